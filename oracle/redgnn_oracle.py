@@ -1,0 +1,215 @@
+"""CPU restatement of RED-GNN's relational-digraph message-passing path.  TEST INFRASTRUCTURE.
+
+This file is the *oracle*: a plain numpy / torch-CPU restatement of the reference algorithm
+(LARS-research/RED-GNN, Static/transductive).  It is the checker for the HIP path and the
+``cpu_baseline`` leg of bench.py.  Only ``tests/``, ``__graft_entry__.smoke()`` and
+``bench.py``'s cpu_baseline may import it; the product package ``red_gnn_amd`` never does.
+
+Parity status: the reference ships no tests or golden vectors, so this oracle
+is pinned by fixtures generated from the reference itself, imported in the build container
+(tests/golden/make_golden.py).  ``load_data.py`` and ``utils.py`` of the reference import
+unmodified, so frontier expansion (a4), graph build (a7) and ranking (a8) are pinned against
+the real code.  ``models.py`` needs the third-party ``torch_scatter`` 2.0.9, which is absent
+offline; the generator substitutes that one op by its definition (zeros + index_add_), so the
+layer arithmetic (a2/a3) is pinned only up to that definition: parity is UNPINNED at the
+torch_scatter boundary.
+
+Every function cites the reference file:line it follows (paths relative to
+Static/transductive/ of the reference).
+"""
+import numpy as np
+import torch
+
+try:  # scipy is on the image; the closed form below is used when it is not
+    from scipy.stats import rankdata as _rankdata
+except Exception:  # pragma: no cover
+    _rankdata = None
+
+
+# --------------------------------------------------------------------------------------
+# graph build  (load_data.py:69-89)
+# --------------------------------------------------------------------------------------
+def double_triple(triples, n_rel):
+    """load_data.py:69-74 — append the inverse triple (t, r+n_rel, h) of every triple."""
+    triples = np.asarray(triples, dtype=np.int64).reshape(-1, 3)
+    inv = np.stack([triples[:, 2], triples[:, 1] + n_rel, triples[:, 0]], 1)
+    return np.concatenate([triples, inv], 0)
+
+
+class OracleGraph:
+    """load_data.py:76-81 — KG rows = doubled triples followed by one identity row per entity
+    (relation id 2*n_rel); ``M_sub`` (one-hot of the head of every row) is held as a CSR by head."""
+
+    def __init__(self, doubled_triples, n_ent, n_rel):
+        doubled_triples = np.asarray(doubled_triples, dtype=np.int64).reshape(-1, 3)
+        ent = np.arange(n_ent, dtype=np.int64)
+        idd = np.stack([ent, np.full(n_ent, 2 * n_rel, dtype=np.int64), ent], 1)
+        self.KG = np.concatenate([doubled_triples, idd], 0)
+        self.n_fact = len(self.KG)
+        self.n_ent, self.n_rel = n_ent, n_rel
+        order = np.argsort(self.KG[:, 0], kind="stable")        # fact rows grouped by head
+        self.rows_by_head = order
+        self.head_ptr = np.zeros(n_ent + 1, dtype=np.int64)
+        np.add.at(self.head_ptr, self.KG[:, 0] + 1, 1)
+        self.head_ptr = np.cumsum(self.head_ptr)
+
+
+def get_neighbors(graph, nodes):
+    """load_data.py:106-131 — frontier expansion.
+
+    nodes: int64 [N,2] = (batch_idx, entity).  Returns (tail_nodes [N',2] sorted
+    lexicographically, sampled_edges [E,6] = (batch, head, rel, tail, head_index, tail_index),
+    old_nodes_new_idx [N]).  The edge order here is fact-row ascending and, inside a fact row,
+    the order of ``nodes`` (the reference leaves the order inside a row unspecified).
+    """
+    nodes = np.asarray(nodes, dtype=np.int64).reshape(-1, 2)
+    n_ent = graph.n_ent
+    deg = graph.head_ptr[nodes[:, 1] + 1] - graph.head_ptr[nodes[:, 1]]
+    tot = int(deg.sum())
+    node_of_edge = np.repeat(np.arange(len(nodes)), deg)
+    start = np.repeat(graph.head_ptr[nodes[:, 1]], deg)
+    off = np.arange(tot) - np.repeat(np.cumsum(deg) - deg, deg)
+    fact_row = graph.rows_by_head[start + off]                  # :116-117 (M_sub . node_1hot, nonzero)
+    o = np.argsort(fact_row, kind="stable")
+    fact_row, node_of_edge = fact_row[o], node_of_edge[o]
+    batch = nodes[node_of_edge, 0]
+    edges = np.concatenate([batch[:, None], graph.KG[fact_row]], 1)   # :118 (batch, head, rel, tail)
+
+    hkey = edges[:, 0] * n_ent + edges[:, 1]                     # :122 unique(dim=0, sorted)
+    tkey = edges[:, 0] * n_ent + edges[:, 3]                     # :123
+    hu, head_index = np.unique(hkey, return_inverse=True)
+    tu, tail_index = np.unique(tkey, return_inverse=True)
+    tail_nodes = np.stack([tu // n_ent, tu % n_ent], 1)
+    edges = np.concatenate([edges, head_index[:, None], tail_index[:, None]], 1)   # :125
+
+    mask = edges[:, 2] == 2 * graph.n_rel                        # :127-129
+    old_idx = np.argsort(head_index[mask], kind="stable")
+    old_nodes_new_idx = tail_index[mask][old_idx]
+    return tail_nodes, edges, old_nodes_new_idx
+
+
+# --------------------------------------------------------------------------------------
+# model  (models.py)
+# --------------------------------------------------------------------------------------
+_ACTS = {"relu": torch.relu, "tanh": torch.tanh, "idd": lambda x: x}
+
+
+def _t(x, dtype):
+    return (x if torch.is_tensor(x) else torch.as_tensor(np.asarray(x))).to(dtype)
+
+
+def gnn_layer_forward(p, prefix, q_rel, hidden, edges, n_node, act, dtype=torch.float32):
+    """models.py:23-43 — one GNNLayer.  ``p`` maps state-dict names to tensors."""
+    g = lambda k: _t(p[prefix + k], dtype)
+    edges = torch.as_tensor(edges, dtype=torch.long)
+    sub, rel, obj, r_idx = edges[:, 4], edges[:, 2], edges[:, 5], edges[:, 0]
+    rela = g("rela_embed.weight")
+    hs = hidden[sub]                                             # :29
+    hr = rela[rel]                                               # :30
+    h_qr = rela[torch.as_tensor(q_rel, dtype=torch.long)][r_idx]  # :32-33
+    message = hs + hr                                            # :35
+    pre = hs @ g("Ws_attn.weight").T + hr @ g("Wr_attn.weight").T \
+        + h_qr @ g("Wqr_attn.weight").T + g("Wqr_attn.bias")
+    alpha = torch.sigmoid(torch.relu(pre) @ g("w_alpha.weight").T + g("w_alpha.bias"))   # :36
+    message = alpha * message                                    # :37
+    agg = torch.zeros(n_node, hidden.shape[1], dtype=dtype).index_add_(0, obj, message)  # :39 scatter-sum
+    return act(agg @ g("W_h.weight").T), agg, alpha              # :41
+
+
+def gru_step(p, x, h, dtype=torch.float32):
+    """models.py:63,83 — single-step nn.GRU (gate rows ordered [r; z; n])."""
+    w_ih, w_hh = _t(p["gate.weight_ih_l0"], dtype), _t(p["gate.weight_hh_l0"], dtype)
+    b_ih, b_hh = _t(p["gate.bias_ih_l0"], dtype), _t(p["gate.bias_hh_l0"], dtype)
+    d = x.shape[1]
+    gi = x @ w_ih.T + b_ih
+    gh = h @ w_hh.T + b_hh
+    r = torch.sigmoid(gi[:, :d] + gh[:, :d])
+    z = torch.sigmoid(gi[:, d:2 * d] + gh[:, d:2 * d])
+    n = torch.tanh(gi[:, 2 * d:] + r * gh[:, 2 * d:])
+    return (1 - z) * n + z * h
+
+
+def forward(p, graph, subs, rels, n_layer, act="relu", dtype=torch.float32, trace=None):
+    """models.py:65-89 — RED_GNN_trans.forward in eval mode (dropout = identity).
+
+    Returns scores_all [B, n_ent].  If ``trace`` is a list, a dict per layer is appended
+    with nodes / edges / old_nodes_new_idx / agg / hidden.
+    """
+    subs = np.asarray(subs, dtype=np.int64)
+    rels = np.asarray(rels, dtype=np.int64)
+    n = len(subs)
+    d = p["W_final.weight"].shape[1]
+    actf = _ACTS[act]
+    h0 = torch.zeros(n, d, dtype=dtype)                          # :72
+    nodes = np.stack([np.arange(n, dtype=np.int64), subs], 1)    # :73
+    hidden = torch.zeros(n, d, dtype=dtype)                      # :74
+    for i in range(n_layer):                                     # :77
+        nodes, edges, old_new = get_neighbors(graph, nodes)      # :78
+        hidden, agg, alpha = gnn_layer_forward(p, "gnn_layers.%d." % i, rels, hidden, edges,
+                                               len(nodes), actf, dtype)   # :80
+        h0n = torch.zeros(len(nodes), d, dtype=dtype)
+        h0n[torch.as_tensor(old_new)] = h0                       # :81 index_copy_
+        hidden = gru_step(p, hidden, h0n, dtype)                 # :82-84 (dropout is identity in eval)
+        h0 = hidden
+        if trace is not None:
+            trace.append(dict(nodes=nodes, edges=edges, old_nodes_new_idx=old_new,
+                              agg=agg, alpha=alpha, hidden=hidden))
+    scores = hidden @ _t(p["W_final.weight"], dtype).T           # :86
+    scores_all = torch.zeros(n, graph.n_ent, dtype=dtype)        # :87
+    scores_all[torch.as_tensor(nodes[:, 0]), torch.as_tensor(nodes[:, 1])] = scores[:, 0]   # :88
+    return scores_all
+
+
+def loss_fn(scores, pos_tail):
+    """base_model.py:58-60 — full-softmax cross entropy, restated literally.
+
+    NOTE the reference keeps ``max_n`` as [n,1] (keepdim) while ``pos_scores`` and the
+    log-sum-exp are [n], so ``-pos + max_n + log(...)`` broadcasts to an [n,n] matrix whose
+    sum is n * sum_i(-s[i,t_i] + max_i + log sum_j exp(s[i,j] - max_i)).  That factor n is
+    part of the reference's behaviour (it scales every gradient) and is kept."""
+    idx = torch.arange(len(scores))
+    pos = scores[idx, torch.as_tensor(pos_tail, dtype=torch.long)]
+    max_n = torch.max(scores, 1, keepdim=True)[0]
+    return torch.sum(-pos + max_n + torch.log(torch.sum(torch.exp(scores - max_n), 1)))
+
+
+# --------------------------------------------------------------------------------------
+# ranking  (utils.py:7-21)
+# --------------------------------------------------------------------------------------
+def cal_ranks(scores, labels, filters):
+    """utils.py:7-14 — filtered ranks of all answers (scipy.rankdata form, as the reference)."""
+    if _rankdata is None:
+        return cal_ranks_closed_form(scores, labels, filters)
+    scores = scores - np.min(scores, axis=1, keepdims=True) + 1e-8
+    full_rank = _rankdata(-scores, method="average", axis=1)
+    filter_scores = scores * filters
+    filter_rank = _rankdata(-filter_scores, method="min", axis=1)
+    ranks = (full_rank - filter_rank + 1) * labels
+    ranks = ranks[np.nonzero(ranks)]
+    return list(ranks)
+
+
+def cal_ranks_closed_form(scores, labels, filters):
+    """The same ranks without sorting:
+    rank(a) = #{j not in filter: s'_j > s'_a} + (#{j: s'_j == s'_a} + 1)/2
+    with s' = fl32(fl32(s - rowmin) + 1e-8).  Answers are a subset of the filter set."""
+    scores = np.asarray(scores)
+    s = scores - np.min(scores, axis=1, keepdims=True) + 1e-8
+    out = []
+    for i in range(len(s)):
+        row = s[i]
+        nf = np.asarray(filters[i]) == 0
+        for a in np.nonzero(labels[i])[0]:
+            gt = np.count_nonzero((row > row[a]) & nf)
+            eq = np.count_nonzero(row == row[a])
+            out.append(gt + (eq + 1) / 2.0)
+    return out
+
+
+def cal_performance(ranks):
+    """utils.py:17-21."""
+    ranks = np.asarray(ranks, dtype=np.float64)
+    mrr = (1.0 / ranks).sum() / len(ranks)
+    h_1 = np.sum(ranks <= 1) * 1.0 / len(ranks)
+    h_10 = np.sum(ranks <= 10) * 1.0 / len(ranks)
+    return mrr, h_1, h_10

@@ -1,0 +1,246 @@
+"""Generate the golden fixtures in this directory from the REFERENCE itself.
+
+Runs only in the build container, where the reference is mounted read-only at
+/root/reference.  It imports the reference's ``load_data`` / ``utils`` / ``models`` modules
+unmodified, runs them on CPU and writes small ``.npz`` fixtures (inputs + expected outputs).
+Nothing of the reference's code is copied: only numbers travel.
+
+Two things the reference needs that this image lacks:
+  * ``torch_scatter`` 2.0.9 (third party, not vendored, not installable offline).  Its single
+    use on the path, ``scatter(src, index=obj, dim=0, dim_size=n, reduce='sum')``
+    (Static/transductive/models.py:39), is registered here as a module object whose ``scatter``
+    is the op's definition: zeros(dim_size, D).index_add_(0, index, src).  Parity of the layer
+    arithmetic is therefore pinned only up to that definition ("unpinned" at that boundary).
+  * a GPU: the model hard-codes ``.cuda()``; this harness makes ``.cuda()`` the identity.
+
+Usage:  python tests/golden/make_golden.py        (writes tests/golden/*.npz)
+"""
+import hashlib
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference/Static/transductive"
+
+sys.dont_write_bytecode = True
+sys.path.insert(0, ROOT)
+
+# --- the one missing third-party op, by definition --------------------------------------
+_scatter_log = []
+
+
+def _scatter(src, index, dim=0, dim_size=None, reduce="sum"):
+    assert dim == 0 and reduce == "sum"
+    out = torch.zeros((dim_size,) + tuple(src.shape[1:]), dtype=src.dtype).index_add_(0, index, src)
+    _scatter_log.append(out.detach().clone())
+    return out
+
+
+_ts = types.ModuleType("torch_scatter")
+_ts.scatter = _scatter
+sys.modules["torch_scatter"] = _ts
+torch.Tensor.cuda = lambda self, *a, **k: self
+torch.nn.Module.cuda = lambda self, *a, **k: self
+
+sys.path.insert(0, REF)
+_cwd = os.getcwd()
+os.chdir(REF)
+import load_data as ref_load_data   # noqa: E402
+import models as ref_models         # noqa: E402
+import utils as ref_utils           # noqa: E402
+os.chdir(_cwd)
+
+from red_gnn_amd.synthetic import make_synthetic_kg, write_task_dir   # noqa: E402
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def edge_multiset_hash(edges):
+    """Order-independent hash of the (batch, head, rel, tail) multiset."""
+    e = np.asarray(edges)[:, :4].astype(np.int64)
+    o = np.lexsort((e[:, 3], e[:, 2], e[:, 1], e[:, 0]))
+    return sha(e[o])
+
+
+class Params:
+    pass
+
+
+def make_params(n_layer, hidden_dim, attn_dim, n_rel, act, dropout=0.0):
+    p = Params()
+    p.n_layer, p.hidden_dim, p.attn_dim, p.n_rel, p.act, p.dropout = n_layer, hidden_dim, attn_dim, n_rel, act, dropout
+    return p
+
+
+def ids_of(loader):
+    return dict(n_ent=np.int64(loader.n_ent), n_rel=np.int64(loader.n_rel),
+                facts=np.array(loader.fact_triple, dtype=np.int32),
+                train=np.array(loader.train_triple, dtype=np.int32),
+                valid=np.array(loader.valid_triple, dtype=np.int32),
+                test=np.array(loader.test_triple, dtype=np.int32))
+
+
+def run_forward(loader, params, subs, rels, mode, seed=1234, keep_edges=False, train_mode=False):
+    """Run the unmodified reference model; capture every per-layer intermediate."""
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    model = ref_models.RED_GNN_trans(params, loader)
+    model.train() if train_mode else model.eval()
+    rec = {}
+    expand_log = []
+    orig = loader.get_neighbors
+
+    def spy(nodes, mode="train"):
+        out = orig(nodes, mode=mode)
+        expand_log.append(out)
+        return out
+
+    loader.get_neighbors = spy
+    layer_out, gru_out = [], []
+    hooks = [l.register_forward_hook(lambda m, i, o: layer_out.append(o.detach().clone())) for l in model.gnn_layers]
+    hooks.append(model.gate.register_forward_hook(lambda m, i, o: gru_out.append(o[0].detach().clone().squeeze(0))))
+    _scatter_log.clear()
+    scores = model(np.asarray(subs), np.asarray(rels), mode=mode)
+    for h in hooks:
+        h.remove()
+    loader.get_neighbors = orig
+    for i, (nodes, edges, old_new) in enumerate(expand_log):
+        rec["L%d_nodes" % i] = nodes.numpy().astype(np.int32)
+        rec["L%d_old_nodes_new_idx" % i] = old_new.numpy().astype(np.int32)
+        rec["L%d_n_edges" % i] = np.int64(edges.shape[0])
+        rec["L%d_edge_hash" % i] = np.array(edge_multiset_hash(edges.numpy()))
+        if keep_edges:
+            rec["L%d_edges" % i] = edges.numpy().astype(np.int32)
+        rec["L%d_agg" % i] = _scatter_log[i].numpy()
+        rec["L%d_layer_out" % i] = layer_out[i].numpy()
+        rec["L%d_hidden" % i] = gru_out[i].numpy()
+    rec["scores"] = scores.detach().numpy()
+    rec["subs"] = np.asarray(subs, dtype=np.int32)
+    rec["rels"] = np.asarray(rels, dtype=np.int32)
+    for k, v in model.state_dict().items():
+        rec["param::" + k] = v.numpy()
+    rec["cfg"] = np.array([params.n_layer, params.hidden_dim, params.attn_dim], dtype=np.int64)
+    rec["act"] = np.array(params.act)
+    rec["mode"] = np.array(mode)
+    return model, scores, rec
+
+
+def eval_queries(loader, which, idx):
+    """(subs, rels, labels, filters) for query indices ``idx`` — what base_model.py:105-115 builds.
+    (loader.get_batch(data='valid'|'test') raises on numpy>=1.24 for ragged answers, so the
+    query/answer lists are read directly.)"""
+    q = loader.valid_q if which == "valid" else loader.test_q
+    a = loader.valid_a if which == "valid" else loader.test_a
+    subs = np.array([q[i][0] for i in idx])
+    rels = np.array([q[i][1] for i in idx])
+    objs = np.zeros((len(idx), loader.n_ent))
+    filt = np.zeros((len(idx), loader.n_ent))
+    for k, i in enumerate(idx):
+        objs[k][a[i]] = 1
+        filt[k][np.array(loader.filters[(subs[k], rels[k])])] = 1
+    return subs, rels, objs, filt
+
+
+def case_tiny(out_dir):
+    kg = make_synthetic_kg(50, 4, 300, seed=7)
+    with tempfile.TemporaryDirectory() as td:
+        write_task_dir(kg, td)
+        loader = ref_load_data.DataLoader(td)
+    params = make_params(3, 16, 5, loader.n_rel, "relu", dropout=0.0)
+    subs, rels, objs, filt = eval_queries(loader, "test", [0, 1, 2, 3])
+    _, scores, rec = run_forward(loader, params, subs, rels, "test", keep_edges=True)
+    rec.update(ids_of(loader))
+    rec["labels"], rec["filters"] = objs.astype(np.uint8), filt.astype(np.uint8)
+    rec["ranks"] = np.array(ref_utils.cal_ranks(scores.detach().numpy(), objs, filt))
+    np.savez_compressed(os.path.join(out_dir, "tiny_fwd.npz"), **rec)
+
+    # backward: train graph, train mode, dropout = 0, loss of base_model.py:58-60
+    trip = loader.train_data[:6]
+    model, scores, rec = run_forward(loader, params, trip[:, 0], trip[:, 1], "train", keep_edges=True, train_mode=True)
+    pos = scores[[torch.arange(len(scores)), torch.LongTensor(trip[:, 2])]]
+    max_n = torch.max(scores, 1, keepdim=True)[0]
+    loss = torch.sum(-pos + max_n + torch.log(torch.sum(torch.exp(scores - max_n), 1)))
+    loss.backward()
+    rec.update(ids_of(loader))
+    rec["tails"] = trip[:, 2].astype(np.int32)
+    rec["loss"] = np.float64(loss.item())
+    for k, v in model.named_parameters():
+        rec["grad::" + k] = v.grad.numpy()
+    np.savez_compressed(os.path.join(out_dir, "tiny_bwd.npz"), **rec)
+
+
+def case_dataset(out_dir, name, n_layer, dims, act, n_q, with_ids=True, light=False):
+    cwd = os.getcwd()
+    os.chdir(REF)
+    loader = ref_load_data.DataLoader(os.path.join("data", name))
+    os.chdir(cwd)
+    if with_ids:
+        np.savez_compressed(os.path.join(out_dir, "%s_ids.npz" % name), **ids_of(loader))
+    subs, rels, objs, filt = eval_queries(loader, "test", list(range(n_q)))
+    for d in dims:
+        params = make_params(n_layer, d, 5, loader.n_rel, act, dropout=0.0)
+        _, scores, rec = run_forward(loader, params, subs, rels, "test")
+        if light:   # sizes + hashes only (large graphs)
+            keep = {}
+            for k, v in rec.items():
+                if k.endswith("_nodes"):
+                    keep[k[:-6] + "_n_nodes"] = np.int64(len(v))
+                    keep[k + "_hash"] = np.array(sha(v.astype(np.int64)))
+                elif k.endswith(("_n_edges", "_edge_hash")) or k.startswith("param::") or k in ("subs", "rels", "cfg", "act", "mode"):
+                    keep[k] = v
+            sc = scores.detach().numpy()
+            keep["score_nnz"] = np.int64(np.count_nonzero(sc))
+            vis = rec["L%d_nodes" % (n_layer - 1)]
+            keep["scores_visited"] = sc[vis[:, 0], vis[:, 1]]
+            rec = keep
+        else:       # keep fixtures small: per-layer hidden only (agg / layer_out stay in the tiny case)
+            last = "L%d_hidden" % (n_layer - 1)
+            rec = {k: v for k, v in rec.items()
+                   if not k.endswith(("_agg", "_layer_out")) and (d == dims[-1] or not k.endswith("_hidden") or k == last)}
+        rec["ranks"] = np.array(ref_utils.cal_ranks(scores.detach().numpy(), objs, filt))
+        rec["labels_idx"] = np.stack(np.nonzero(objs), 1).astype(np.int32)
+        rec["filters_idx"] = np.stack(np.nonzero(filt), 1).astype(np.int32)
+        np.savez_compressed(os.path.join(out_dir, "%s_d%d.npz" % (name, d)), **rec)
+
+
+def case_ranks(out_dir):
+    rng = np.random.default_rng(5)
+    n, m = 12, 300
+    scores = np.zeros((n, m), dtype=np.float32)
+    for i in range(n):
+        k = int(rng.integers(1, 120))
+        cols = rng.choice(m, k, replace=False)
+        vals = rng.standard_normal(k).astype(np.float32)
+        if i % 3 == 0:
+            vals = np.round(vals, 1)            # many exact ties among visited entities
+        scores[i, cols] = vals
+    labels = np.zeros((n, m))
+    filters = np.zeros((n, m))
+    for i in range(n):
+        f = rng.choice(m, int(rng.integers(1, 25)), replace=False)
+        filters[i, f] = 1
+        labels[i, f[: int(rng.integers(1, len(f) + 1))]] = 1
+    ranks = np.array(ref_utils.cal_ranks(scores, labels, filters))
+    perf = np.array(ref_utils.cal_performance(ranks))
+    np.savez_compressed(os.path.join(out_dir, "ranks.npz"), scores=scores, labels=labels.astype(np.uint8),
+                        filters=filters.astype(np.uint8), ranks=ranks, perf=perf)
+
+
+if __name__ == "__main__":
+    out = HERE
+    case_tiny(out)
+    case_ranks(out)
+    case_dataset(out, "family", 3, [48, 64], "relu", 8)
+    case_dataset(out, "umls", 4, [48], "relu", 4)
+    case_dataset(out, "WN18RR", 5, [48], "tanh", 4, light=True)
+    for f in sorted(os.listdir(out)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(out, f)))

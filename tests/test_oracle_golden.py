@@ -1,0 +1,95 @@
+"""The oracle (CPU restatement) against fixtures generated from the reference itself.
+
+These pin the oracle: node sets / edge multisets / old_nodes_new_idx bit-exact, hidden and
+scores within fp32 tolerance, ranks exact.  Tolerance: rtol 1e-4, atol 1e-5 on fp32 values
+(SURVEY.md §7 "Determinism / tolerance")."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import redgnn_oracle as orc
+from tests import _util as U
+
+RTOL, ATOL = 1e-4, 1e-5
+
+
+def _run(fx, ids, dtype=torch.float32):
+    n_layer = int(fx["cfg"][0])
+    g = U.oracle_graph(ids, str(fx["mode"]))
+    trace = []
+    scores = orc.forward(U.params_of(fx), g, fx["subs"], fx["rels"], n_layer, act=str(fx["act"]), dtype=dtype, trace=trace)
+    return g, scores, trace
+
+
+@pytest.mark.parametrize("name", ["tiny_fwd.npz", "tiny_bwd.npz"])
+def test_tiny_every_intermediate(name):
+    fx = U.load(name)
+    g, scores, trace = _run(fx, fx)
+    for i, t in enumerate(trace):
+        assert np.array_equal(t["nodes"], fx["L%d_nodes" % i])
+        assert np.array_equal(t["old_nodes_new_idx"], fx["L%d_old_nodes_new_idx" % i])
+        assert np.array_equal(U.sorted_edges(t["edges"]), U.sorted_edges(fx["L%d_edges" % i]))
+        np.testing.assert_allclose(t["agg"].numpy(), fx["L%d_agg" % i], rtol=RTOL, atol=ATOL)
+        np.testing.assert_allclose(t["hidden"].numpy(), fx["L%d_hidden" % i], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(scores.numpy(), fx["scores"], rtol=RTOL, atol=ATOL)
+    assert np.array_equal(scores.numpy() == 0, fx["scores"] == 0)
+
+
+def test_tiny_ranks():
+    fx = U.load("tiny_fwd.npz")
+    ranks = orc.cal_ranks(fx["scores"], fx["labels"].astype(np.float64), fx["filters"].astype(np.float64))
+    assert np.array_equal(np.array(ranks), fx["ranks"])
+    ranks2 = orc.cal_ranks_closed_form(fx["scores"], fx["labels"], fx["filters"])
+    assert np.array_equal(np.array(ranks2), fx["ranks"])
+
+
+def test_tiny_backward():
+    fx = U.load("tiny_bwd.npz")
+    p = {k: torch.tensor(v, requires_grad=True) for k, v in U.params_of(fx).items()}
+    g = U.oracle_graph(fx, "train")
+    scores = orc.forward(p, g, fx["subs"], fx["rels"], int(fx["cfg"][0]), act=str(fx["act"]))
+    loss = orc.loss_fn(scores, fx["tails"])
+    assert abs(loss.item() - float(fx["loss"])) < 1e-4 * max(1.0, abs(float(fx["loss"])))
+    loss.backward()
+    for k, gref in U.grads_of(fx).items():
+        np.testing.assert_allclose(p[k].grad.numpy(), gref, rtol=1e-3, atol=1e-5, err_msg=k)
+
+
+@pytest.mark.parametrize("name,ids", [("family_d48.npz", "family_ids.npz"), ("family_d64.npz", "family_ids.npz"),
+                                      ("umls_d48.npz", "umls_ids.npz")])
+def test_dataset_cases(name, ids):
+    fx, ids = U.load(name), U.load(ids)
+    g, scores, trace = _run(fx, ids)
+    for i, t in enumerate(trace):
+        assert np.array_equal(t["nodes"], fx["L%d_nodes" % i])
+        assert np.array_equal(t["old_nodes_new_idx"], fx["L%d_old_nodes_new_idx" % i])
+        assert len(t["edges"]) == int(fx["L%d_n_edges" % i])
+        assert U.edge_multiset_hash(t["edges"]) == str(fx["L%d_edge_hash" % i])
+        if "L%d_hidden" % i in fx:
+            np.testing.assert_allclose(t["hidden"].numpy(), fx["L%d_hidden" % i], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(scores.numpy(), fx["scores"], rtol=RTOL, atol=ATOL)
+    n_ent = int(ids["n_ent"])
+    labels = np.zeros((len(fx["subs"]), n_ent)); labels[fx["labels_idx"][:, 0], fx["labels_idx"][:, 1]] = 1
+    filt = np.zeros((len(fx["subs"]), n_ent)); filt[fx["filters_idx"][:, 0], fx["filters_idx"][:, 1]] = 1
+    assert np.array_equal(np.array(orc.cal_ranks(fx["scores"], labels, filt)), fx["ranks"])
+    assert np.array_equal(np.array(orc.cal_ranks_closed_form(fx["scores"], labels, filt)), fx["ranks"])
+
+
+def test_wn18rr_node_sets():
+    fx, ids = U.load("WN18RR_d48.npz"), U.load("WN18RR_ids.npz")
+    g, scores, trace = _run(fx, ids)
+    for i, t in enumerate(trace):
+        assert len(t["nodes"]) == int(fx["L%d_n_nodes" % i])
+        assert U.sha(t["nodes"].astype(np.int64)) == str(fx["L%d_nodes_hash" % i])
+        assert len(t["edges"]) == int(fx["L%d_n_edges" % i])
+        assert U.edge_multiset_hash(t["edges"]) == str(fx["L%d_edge_hash" % i])
+    vis = trace[-1]["nodes"]
+    np.testing.assert_allclose(scores.numpy()[vis[:, 0], vis[:, 1]], fx["scores_visited"], rtol=RTOL, atol=ATOL)
+
+
+def test_ranks_heavy_ties():
+    fx = U.load("ranks.npz")
+    lab, fil = fx["labels"].astype(np.float64), fx["filters"].astype(np.float64)
+    assert np.array_equal(np.array(orc.cal_ranks(fx["scores"], lab, fil)), fx["ranks"])
+    assert np.array_equal(np.array(orc.cal_ranks_closed_form(fx["scores"], lab, fil)), fx["ranks"])
+    np.testing.assert_allclose(np.array(orc.cal_performance(fx["ranks"])), fx["perf"], rtol=1e-12)
