@@ -1,0 +1,127 @@
+/*
+ * redgnn.h — C-ABI of the MI355X-native RED-GNN hot path (libredgnn.so).
+ *
+ * The reference (LARS-research/RED-GNN) is pure Python and has no FFI; its boundary is the
+ * nn.Module API of RED_GNN_trans plus the DataLoader.get_neighbors callback
+ * (Static/transductive/models.py:45-89, load_data.py:106-131).  This header is the native
+ * boundary *behind* that API: every entry point names the reference code it replaces.
+ * All paths below are relative to Static/transductive/ of the reference.
+ *
+ * Conventions
+ *   - plain C types only: device pointers (const float* / const int32_t*), sizes, an opaque
+ *     stream (hipStream_t passed as void*).  No torch types.
+ *   - every function returns 0 on success, non-zero on error; rg_last_error() then returns a
+ *     thread-local message.  Nothing is printed, nothing aborts.
+ *   - buffers are caller-owned.  The library allocates device memory only inside rg_graph
+ *     handles; per-batch state lives in a caller-provided workspace (rg_frontier).
+ *   - launches go to the stream passed in and are asynchronous, except rg_frontier_expand,
+ *     which returns the new node/edge counts and therefore synchronises that stream once.
+ *   - indices are int32 (requires B*n_ent < 2^31 and n_fact < 2^31; checked).
+ *   - node order is the reference's: sorted by (batch_idx, entity); node id = rank in that order.
+ */
+#ifndef REDGNN_H
+#define REDGNN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rg_graph rg_graph;        /* device-resident KG: CSR by head and CSR by tail */
+typedef struct rg_frontier rg_frontier;  /* per-batch visited-set state inside a caller workspace */
+
+const char* rg_last_error(void);
+int rg_version(void);
+
+/* ---- graph build: replaces load_data.py:69-81 (double_triple + load_graph) ------------------
+ * triples: HOST int32 [n,3] = (head, rel, tail) base triples.  If add_inverse != 0 the inverse
+ * (tail, rel+n_rel, head) of every triple is added (load_data.py:69-74).  One identity row
+ * (e, 2*n_rel, e) per entity is always added (load_data.py:77-79).  Fact-row order is kept
+ * inside every CSR row so sums are reproducible. */
+int rg_graph_create(int32_t n_ent, int32_t n_rel, const int32_t* triples_host, int64_t n,
+                    int add_inverse, rg_graph** out);
+int rg_graph_destroy(rg_graph* g);
+int64_t rg_graph_n_fact(const rg_graph* g);      /* rows incl. inverse + identity (load_data.py:80) */
+/* copy the device CSR back (tests): ptr arrays have n_ent+1 entries, pair arrays 2*n_fact. */
+int rg_graph_export(const rg_graph* g, int32_t* out_ptr_host, int32_t* out_rel_tail_host,
+                    int32_t* in_ptr_host, int32_t* in_head_rel_host);
+
+/* ---- frontier expansion: replaces DataLoader.get_neighbors, load_data.py:106-131 ------------
+ * A frontier keeps `n_levels` visited-set snapshots: level 0 = the query nodes, level k = after
+ * k hops.  Levels are stored modulo n_levels: 2 is enough for inference (ping-pong), training
+ * keeps n_layer+1 so that rg_layer_bwd can revisit every hop. */
+size_t rg_frontier_workspace_bytes(int32_t n_ent, int32_t batch, int32_t n_levels);
+/* workspace: device memory of at least rg_frontier_workspace_bytes(), 256-B aligned. */
+int rg_frontier_create(int32_t n_ent, int32_t batch, int32_t n_levels, void* workspace_dev,
+                       size_t workspace_bytes, rg_frontier** out);
+int rg_frontier_destroy(rg_frontier* f);
+/* level 0 frontier {(b, q_sub[b])}: models.py:73.  q_sub: device int32 [batch]. */
+int rg_frontier_reset(rg_frontier* f, const int32_t* q_sub_dev, void* stream);
+/* level 0 frontier from an arbitrary node set (the general form get_neighbors accepts,
+ * load_data.py:106,115): nodes device int32 [n,2] = (batch, entity), batch < `batch`, no duplicates. */
+int rg_frontier_reset_nodes(rg_frontier* f, const int32_t* nodes_dev, int64_t n, void* stream);
+/* one hop: new frontier = tails of all out-edges of the current one (identity edges keep the
+ * old nodes).  counts_host[0] = N_new, counts_host[1] = E (edges of this hop),
+ * counts_host[2] = N_old, counts_host[3] = new level.  Synchronises `stream`. */
+int rg_frontier_expand(rg_frontier* f, const rg_graph* g, int64_t* counts_host, void* stream);
+/* nodes of the current level: nodes_out int32 [N_new,2] = (batch, entity) sorted
+ * (== tail_nodes, load_data.py:123); prev_idx_out int32 [N_new] = index of the node in the
+ * previous level or -1; old_nodes_new_idx_out int32 [N_old] (load_data.py:127-129).
+ * Any pointer may be NULL. */
+int rg_frontier_nodes(const rg_frontier* f, int32_t* nodes_out, int32_t* prev_idx_out,
+                      int32_t* old_nodes_new_idx_out, void* stream);
+/* materialised edge list of hop `level-1 -> level` (API parity with sampled_edges,
+ * load_data.py:118-125): edges_out int32 [E,6] = (batch, head, rel, tail, old_idx, new_idx),
+ * grouped by new_idx (destination-segmented); row_ptr_out int32 [N_new+1].
+ * nodes_new: device int32 [N_new,2] from rg_frontier_nodes.  scratch: device memory of
+ * rg_frontier_edges_scratch_bytes(N_new) bytes. */
+size_t rg_frontier_edges_scratch_bytes(int64_t n_new);
+int rg_frontier_edges(const rg_frontier* f, const rg_graph* g, int32_t level,
+                      const int32_t* nodes_new, int64_t n_new, int32_t* edges_out,
+                      int32_t* row_ptr_out, void* scratch_dev, void* stream);
+
+/* ---- layer forward: replaces GNNLayer.forward models.py:29-39 incl. torch_scatter.scatter ----
+ * For hop level-1 -> level:
+ * agg[o] = sum over in-edges e=(s,r,o) of alpha_e * (hidden[s] + rela[r]),
+ * alpha_e = sigmoid(w_alpha . relu(a_s[s] + a_r[r] + a_q[b]) + b_alpha), with the hoisted
+ * projections a_s = hidden Ws^T [N_old,ap], a_r = rela Wr^T [2R+1,ap], a_q = rela[q_rel] Wqr^T + b [B,ap]
+ * (ap = attention dim padded to a multiple of 4, pad columns zero).  Edges are enumerated
+ * from the CSR-by-tail of `g` and the frontier bitmaps; no edge list is materialised.
+ * nodes_new int32 [N_new,2]; hidden [N_old, ld], rela [2R+1, ld], agg_out [N_new, ld];
+ * ld % 4 == 0, ld >= d, pad columns of hidden/rela must be zero. */
+int rg_layer_fwd(const rg_frontier* f, const rg_graph* g, int32_t level,
+                 const int32_t* nodes_new, int64_t n_new,
+                 const float* hidden, const float* rela, int32_t d, int32_t ld,
+                 const float* a_s, const float* a_r, const float* a_q, int32_t ap,
+                 const float* w_alpha, const float* b_alpha, int32_t attn_dim,
+                 float* agg_out, void* stream);
+
+/* ---- layer backward: adjoint of rg_layer_fwd (autograd of models.py:29-39) --------------------
+ * nodes_old int32 [N_old,2] (level-1).  grad_agg [N_new, ld].  grad_hidden [N_old, ld] and
+ * grad_a_s [N_old, ap] are WRITTEN; grad_rela [2R+1, ld], grad_a_r [2R+1, ap], grad_a_q [B, ap],
+ * grad_w_alpha [attn_dim], grad_b_alpha [1] are ACCUMULATED into (caller zero-fills). */
+int rg_layer_bwd(const rg_frontier* f, const rg_graph* g, int32_t level,
+                 const int32_t* nodes_old, int64_t n_old,
+                 const float* hidden, const float* rela, int32_t d, int32_t ld,
+                 const float* a_s, const float* a_r, const float* a_q, int32_t ap,
+                 const float* w_alpha, const float* b_alpha, int32_t attn_dim,
+                 const float* grad_agg,
+                 float* grad_hidden, float* grad_rela, float* grad_a_s, float* grad_a_r,
+                 float* grad_a_q, float* grad_w_alpha, float* grad_b_alpha, void* stream);
+
+/* ---- filtered ranking: replaces utils.py:7-14 cal_ranks (+ the filter loop base_model.py:107-115)
+ * scores device fp32 [B, n_ent]; answers / filters as CSR over queries (device int32):
+ * ans_ptr [B+1], ans_idx [ans_ptr[B]], filt_ptr [B+1], filt_idx [..].  ranks_out device fp32
+ * [ans_ptr[B]] in (query, answer-list) order: rank = #{j not in filter: s'_j > s'_a} +
+ * (#{j: s'_j == s'_a} + 1)/2 with s' = fl32(fl32(s - rowmin) + 1e-8). */
+int rg_rank(const float* scores, int32_t batch, int32_t n_ent,
+            const int32_t* ans_ptr, const int32_t* ans_idx,
+            const int32_t* filt_ptr, const int32_t* filt_idx,
+            float* ranks_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REDGNN_H */

@@ -1,0 +1,79 @@
+// Shared internals of libredgnn.so (not part of the C-ABI; the ABI is include/redgnn.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "redgnn.h"
+
+namespace rg {
+
+void set_error(const char* fmt, ...);
+
+#define RG_CHECK(cond, ...)                 \
+  do {                                      \
+    if (!(cond)) {                          \
+      ::rg::set_error(__VA_ARGS__);         \
+      return 1;                             \
+    }                                       \
+  } while (0)
+
+#define RG_HIP(expr)                                                                  \
+  do {                                                                                \
+    hipError_t e_ = (expr);                                                           \
+    if (e_ != hipSuccess) {                                                           \
+      ::rg::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                      __LINE__);                                                      \
+      return 1;                                                                       \
+    }                                                                                 \
+  } while (0)
+
+#define RG_LAUNCH_CHECK() RG_HIP(hipGetLastError())
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- exclusive scan (device) --------------------------------------------------------------
+// out[i] = sum_{j<i} f(in[j]);  *total_dev = sum of all.  `POPC` selects f = popcount.
+// scratch: int32 device buffer of scan_scratch_elems(n) elements.
+size_t scan_scratch_elems(int64_t n);
+int scan_exclusive(const uint32_t* in, int32_t* out, int64_t n, bool popc, int32_t* total_dev,
+                   int32_t* scratch, hipStream_t s);
+
+}  // namespace rg
+
+// ---- handles ----------------------------------------------------------------------------------
+struct rg_graph {
+  int32_t n_ent = 0, n_rel = 0;
+  int64_t n_fact = 0;
+  int32_t max_in_deg = 0, max_out_deg = 0;
+  // CSR by head: out_ptr[n_ent+1], out_rt[n_fact] = {rel, tail}
+  int32_t* out_ptr = nullptr;
+  int2* out_rt = nullptr;
+  // CSR by tail: in_ptr[n_ent+1], in_hr[n_fact] = {head, rel}
+  int32_t* in_ptr = nullptr;
+  int2* in_hr = nullptr;
+};
+
+// Frontier state, all inside the caller's workspace.
+//   bitsT[2]   : entity-major visited bitmaps  uint32 [n_ent][BW]   (BW = ceil(B/32)); ping-pong
+//   bm[level]  : batch-major packed {word, exclusive popcount prefix} int2 [B][W]  (W = ceil(n_ent/32));
+//                prefix runs over the flattened [B][W] array, so rank(b,e) = prefix + popc(word below e)
+//                is the node id in the reference's (batch, entity) order.
+constexpr int RG_MAX_LEVELS = 16;
+struct rg_frontier {
+  int32_t n_ent = 0, B = 0, BW = 0, W = 0, n_levels = 0;
+  uint32_t* bitsT[2] = {nullptr, nullptr};
+  int2* bm[RG_MAX_LEVELS] = {};
+  uint32_t* words_tmp = nullptr;     // [B][W] batch-major words before packing
+  int32_t* prefix_tmp = nullptr;     // [B][W]
+  int32_t* scan_scratch = nullptr;
+  int32_t* counters = nullptr;       // device: [0]=N (int32), [1]=error flag, [2..3]=E (uint64)
+  int64_t* counts_pinned = nullptr;  // host pinned [4]
+  int level = -1;                    // newest level (absolute, not modulo)
+  int tcur = 0;                      // which bitsT holds the newest level
+  int64_t n_nodes[RG_MAX_LEVELS] = {};  // per slot
+  int64_t n_edges = 0;
+  const int2* bm_of(int lvl) const { return bm[lvl % n_levels]; }
+};

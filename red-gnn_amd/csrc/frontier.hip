@@ -1,0 +1,361 @@
+// Frontier expansion on the device.
+// Replaces DataLoader.get_neighbors (Static/transductive/load_data.py:106-131): the scipy
+// one-hot SpMM + np.nonzero + two torch.unique(dim=0) sorts become bit-parallel set algebra:
+//   * the visited set of all B queries is an entity-major bitmap [n_ent][B bits]; one hop is
+//     new[t] = OR_{h in in(t)} old[h]  (B queries per 32-bit word; identity rows keep old nodes),
+//   * transposed to batch-major words, a popcount prefix sum gives every (batch, entity) pair its
+//     rank in the reference's sorted order (torch.unique(dim=0, sorted=True), load_data.py:122-123)
+//     without sorting anything.
+#include <string.h>
+
+#include "common.h"
+
+namespace {
+
+// ---- level 0: one node (b, q_sub[b]) per query ---------------------------------------------------
+__global__ void reset_kernel(const int32_t* __restrict__ q_sub, int B, int n_ent, int BW,
+                             uint32_t* __restrict__ bitsT, int32_t* counters) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int e = q_sub[b];
+  if (e < 0 || e >= n_ent) { atomicOr((unsigned*)&counters[1], 1u); return; }
+  atomicOr(&bitsT[(int64_t)e * BW + (b >> 5)], 1u << (b & 31));
+}
+
+__global__ void reset_nodes_kernel(const int32_t* __restrict__ nodes, int64_t n, int B, int n_ent, int BW,
+                                   uint32_t* __restrict__ bitsT, int32_t* counters) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int b = nodes[2 * i], e = nodes[2 * i + 1];
+  if (e < 0 || e >= n_ent || b < 0 || b >= B) { atomicOr((unsigned*)&counters[1], 1u); return; }
+  atomicOr(&bitsT[(int64_t)e * BW + (b >> 5)], 1u << (b & 31));
+}
+
+// ---- one hop on the entity-major bitmap: new[t] = OR over in-edges (h -> t) of old[h] --------------
+// One wave per entity t.  WL lanes span the B/32 words of a row, 64/WL lanes stride over in-edges.
+__global__ __launch_bounds__(256) void hop_or_kernel(const int32_t* __restrict__ in_ptr, const int2* __restrict__ in_hr,
+                                                     const uint32_t* __restrict__ oldT, uint32_t* __restrict__ newT,
+                                                     int n_ent, int BW, int WL) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (wave >= n_ent) return;
+  const int t = wave;
+  const int wl = lane & (WL - 1);
+  const int el = lane / WL, EL = 64 / WL;
+  const int beg = in_ptr[t], end = in_ptr[t + 1];
+  for (int w0 = 0; w0 < BW; w0 += WL) {
+    const int w = w0 + wl;
+    uint32_t acc = 0;
+    if (w < BW) {
+      for (int j = beg + el; j < end; j += EL) acc |= oldT[(int64_t)in_hr[j].x * BW + w];
+    }
+    for (int o = WL; o < 64; o <<= 1) acc |= __shfl_xor(acc, o, 64);
+    if (el == 0 && w < BW) newT[(int64_t)t * BW + w] = acc;
+  }
+}
+
+// ---- E = sum over visited (b,h) of outdeg(h) -----------------------------------------------------
+__global__ __launch_bounds__(256) void count_edges_kernel(const int32_t* __restrict__ out_ptr,
+                                                          const uint32_t* __restrict__ oldT, int n_ent, int BW,
+                                                          unsigned long long* total) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long v = 0;
+  if (i < (int64_t)n_ent * BW) {
+    const int h = (int)(i / BW);
+    v = (unsigned long long)(out_ptr[h + 1] - out_ptr[h]) * __popc(oldT[i]);
+  }
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  __shared__ unsigned long long ws[4];
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long s = ws[0] + ws[1] + ws[2] + ws[3];
+    if (s) atomicAdd(total, s);
+  }
+}
+
+// ---- 32x32 bit transposes: entity-major [n_ent][BW] -> batch-major words [B][W] --------------------
+// One wave per (batch word bw, pair of entity words): lane l holds row e = 64*pair + l.
+__global__ __launch_bounds__(256) void transpose_kernel(const uint32_t* __restrict__ bitsT, uint32_t* __restrict__ words,
+                                                        int n_ent, int B, int BW, int W, int n_pairs) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (wave >= BW * n_pairs) return;
+  const int bw = wave / n_pairs, pair = wave - bw * n_pairs;
+  const int e = pair * 64 + lane;
+  const uint32_t v = (e < n_ent) ? bitsT[(int64_t)e * BW + bw] : 0u;
+  uint32_t lo = 0, hi = 0;
+#pragma unroll
+  for (int b = 0; b < 32; ++b) {
+    const unsigned long long m = __ballot((v >> b) & 1u);
+    if (lane == b) { lo = (uint32_t)m; hi = (uint32_t)(m >> 32); }
+  }
+  const int batch = bw * 32 + lane;
+  if (lane < 32 && batch < B) {
+    const int ew = pair * 2;
+    words[(int64_t)batch * W + ew] = lo;
+    if (ew + 1 < W) words[(int64_t)batch * W + ew + 1] = hi;
+  }
+}
+
+__global__ void pack_kernel(const uint32_t* __restrict__ words, const int32_t* __restrict__ prefix,
+                            int2* __restrict__ bm, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) bm[i] = make_int2((int)words[i], prefix[i]);
+}
+
+// ---- node list of the newest level + links to the previous level -----------------------------------
+__global__ void emit_nodes_kernel(const int2* __restrict__ bm_new, const int2* __restrict__ bm_old, int B, int W,
+                                  int32_t* __restrict__ nodes, int32_t* __restrict__ prev_idx,
+                                  int32_t* __restrict__ old_new) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)B * W) return;
+  const int2 nw = bm_new[i];
+  uint32_t bits = (uint32_t)nw.x;
+  if (!bits) return;
+  const int b = (int)(i / W), w = (int)(i - (int64_t)b * W);
+  const int2 ow = bm_old ? bm_old[i] : make_int2(0, 0);
+  int idx = nw.y;
+  while (bits) {
+    const int pos = __ffs(bits) - 1;
+    bits &= bits - 1;
+    if (nodes) { nodes[2 * (int64_t)idx] = b; nodes[2 * (int64_t)idx + 1] = w * 32 + pos; }
+    int prev = -1;
+    if (((uint32_t)ow.x >> pos) & 1u) prev = ow.y + __popc((uint32_t)ow.x & ((1u << pos) - 1u));
+    if (prev_idx) prev_idx[idx] = prev;
+    if (old_new && prev >= 0) old_new[prev] = idx;
+    ++idx;
+  }
+}
+
+// ---- materialised edges (compatibility path) -------------------------------------------------------
+__device__ __forceinline__ int rank_in(const int2* __restrict__ bm, int b, int W, int e, bool* present) {
+  const int2 wp = bm[(int64_t)b * W + (e >> 5)];
+  const uint32_t word = (uint32_t)wp.x;
+  *present = (word >> (e & 31)) & 1u;
+  return wp.y + __popc(word & ((1u << (e & 31)) - 1u));
+}
+
+__global__ void edge_count_kernel(const int32_t* __restrict__ nodes_new, int64_t n_new, const int32_t* __restrict__ in_ptr,
+                                  const int2* __restrict__ in_hr, const int2* __restrict__ bm_old, int W,
+                                  uint32_t* __restrict__ deg) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_new) return;
+  const int b = nodes_new[2 * i], t = nodes_new[2 * i + 1];
+  int c = 0;
+  for (int j = in_ptr[t]; j < in_ptr[t + 1]; ++j) {
+    bool p;
+    rank_in(bm_old, b, W, in_hr[j].x, &p);
+    c += p;
+  }
+  deg[i] = c;
+}
+
+__global__ void edge_fill_kernel(const int32_t* __restrict__ nodes_new, int64_t n_new, const int32_t* __restrict__ in_ptr,
+                                 const int2* __restrict__ in_hr, const int2* __restrict__ bm_old, int W,
+                                 const int32_t* __restrict__ row_ptr, int32_t* __restrict__ edges) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_new) return;
+  const int b = nodes_new[2 * i], t = nodes_new[2 * i + 1];
+  int64_t o = row_ptr[i];
+  for (int j = in_ptr[t]; j < in_ptr[t + 1]; ++j) {
+    const int2 hr = in_hr[j];
+    bool p;
+    const int s = rank_in(bm_old, b, W, hr.x, &p);
+    if (p) {
+      int32_t* e = edges + 6 * o;
+      e[0] = b; e[1] = hr.x; e[2] = hr.y; e[3] = t; e[4] = s; e[5] = (int32_t)i;
+      ++o;
+    }
+  }
+}
+
+__global__ void set_last_kernel(int32_t* row_ptr, int64_t n, const int32_t* total) { row_ptr[n] = *total; }
+
+size_t ws_layout(int32_t n_ent, int32_t B, int32_t n_levels, size_t* off /*[8]*/) {
+  const size_t BW = (B + 31) / 32, W = (n_ent + 31) / 32;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { size_t r = o; o = rg::align_up(o + bytes, 256); return r; };
+  off[0] = take((size_t)n_ent * BW * 4);                     // bitsT[0]
+  off[1] = take((size_t)n_ent * BW * 4);                     // bitsT[1]
+  off[2] = take((size_t)B * W * 4);                          // words_tmp
+  off[3] = take((size_t)B * W * 4);                          // prefix_tmp
+  off[4] = take(rg::scan_scratch_elems((int64_t)B * W) * 4); // scan scratch
+  off[5] = take(64);                                         // counters
+  off[6] = take((size_t)n_levels * B * W * 8);               // bm levels
+  return o;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t rg_frontier_workspace_bytes(int32_t n_ent, int32_t batch, int32_t n_levels) {
+  if (n_ent <= 0 || batch <= 0 || n_levels < 2 || n_levels > RG_MAX_LEVELS) return 0;
+  size_t off[8];
+  return ws_layout(n_ent, batch, n_levels, off);
+}
+
+int rg_frontier_create(int32_t n_ent, int32_t batch, int32_t n_levels, void* ws, size_t ws_bytes, rg_frontier** out) {
+  RG_CHECK(out != nullptr, "rg_frontier_create: out is NULL");
+  *out = nullptr;
+  RG_CHECK(n_ent > 0 && batch > 0, "rg_frontier_create: n_ent=%d batch=%d must be positive", n_ent, batch);
+  RG_CHECK(n_levels >= 2 && n_levels <= RG_MAX_LEVELS, "rg_frontier_create: n_levels=%d not in [2,%d]", n_levels, RG_MAX_LEVELS);
+  RG_CHECK((int64_t)n_ent * batch < ((int64_t)1 << 31), "rg_frontier_create: batch*n_ent = %lld does not fit int32",
+           (long long)n_ent * batch);
+  size_t off[8];
+  const size_t need = ws_layout(n_ent, batch, n_levels, off);
+  RG_CHECK(ws != nullptr && ws_bytes >= need, "rg_frontier_create: workspace %zu B < required %zu B", ws_bytes, need);
+  RG_CHECK(((uintptr_t)ws & 255) == 0, "rg_frontier_create: workspace must be 256-B aligned");
+  rg_frontier* f = new rg_frontier();
+  f->n_ent = n_ent; f->B = batch; f->BW = (batch + 31) / 32; f->W = (n_ent + 31) / 32; f->n_levels = n_levels;
+  char* base = (char*)ws;
+  f->bitsT[0] = (uint32_t*)(base + off[0]);
+  f->bitsT[1] = (uint32_t*)(base + off[1]);
+  f->words_tmp = (uint32_t*)(base + off[2]);
+  f->prefix_tmp = (int32_t*)(base + off[3]);
+  f->scan_scratch = (int32_t*)(base + off[4]);
+  f->counters = (int32_t*)(base + off[5]);
+  for (int l = 0; l < n_levels; ++l) f->bm[l] = (int2*)(base + off[6] + (size_t)l * batch * f->W * 8);
+  if (hipHostMalloc((void**)&f->counts_pinned, 8 * sizeof(int64_t), hipHostMallocDefault) != hipSuccess) {
+    delete f;
+    rg::set_error("rg_frontier_create: hipHostMalloc failed");
+    return 1;
+  }
+  *out = f;
+  return 0;
+}
+
+int rg_frontier_destroy(rg_frontier* f) {
+  if (!f) return 0;
+  if (f->counts_pinned) (void)hipHostFree(f->counts_pinned);
+  delete f;
+  return 0;
+}
+
+// bitsT[tcur] -> bm[level % n_levels] with prefix; leaves N in counters[0]
+static int build_level(rg_frontier* f, hipStream_t s) {
+  const int n_pairs = (f->W + 1) / 2;
+  const int64_t waves = (int64_t)f->BW * n_pairs;
+  hipLaunchKernelGGL(transpose_kernel, dim3(rg::ceil_div(waves, 4)), dim3(256), 0, s, f->bitsT[f->tcur], f->words_tmp,
+                     f->n_ent, f->B, f->BW, f->W, n_pairs);
+  RG_LAUNCH_CHECK();
+  const int64_t nw = (int64_t)f->B * f->W;
+  if (rg::scan_exclusive(f->words_tmp, f->prefix_tmp, nw, true, &f->counters[0], f->scan_scratch, s)) return 1;
+  hipLaunchKernelGGL(pack_kernel, dim3(rg::ceil_div(nw, 256)), dim3(256), 0, s, f->words_tmp, f->prefix_tmp,
+                     f->bm[f->level % f->n_levels], nw);
+  RG_LAUNCH_CHECK();
+  return 0;
+}
+
+int rg_frontier_reset(rg_frontier* f, const int32_t* q_sub, void* stream) {
+  RG_CHECK(f && q_sub, "rg_frontier_reset: NULL argument");
+  hipStream_t s = (hipStream_t)stream;
+  f->level = 0; f->tcur = 0; f->n_edges = 0;
+  RG_HIP(hipMemsetAsync(f->bitsT[0], 0, (size_t)f->n_ent * f->BW * 4, s));
+  RG_HIP(hipMemsetAsync(f->counters, 0, 64, s));
+  hipLaunchKernelGGL(reset_kernel, dim3(rg::ceil_div(f->B, 256)), dim3(256), 0, s, q_sub, f->B, f->n_ent, f->BW,
+                     f->bitsT[0], f->counters);
+  RG_LAUNCH_CHECK();
+  if (build_level(f, s)) return 1;
+  RG_HIP(hipMemcpyAsync(&f->counters[4], &f->counters[0], 4, hipMemcpyDeviceToDevice, s));
+  f->n_nodes[0] = f->B;   // one node per query; an out-of-range q_sub is reported by the next expand
+  return 0;
+}
+
+int rg_frontier_reset_nodes(rg_frontier* f, const int32_t* nodes, int64_t n, void* stream) {
+  RG_CHECK(f && (nodes || n == 0) && n >= 0, "rg_frontier_reset_nodes: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  f->level = 0; f->tcur = 0; f->n_edges = 0;
+  RG_HIP(hipMemsetAsync(f->bitsT[0], 0, (size_t)f->n_ent * f->BW * 4, s));
+  RG_HIP(hipMemsetAsync(f->counters, 0, 64, s));
+  if (n > 0) {
+    hipLaunchKernelGGL(reset_nodes_kernel, dim3(rg::ceil_div(n, 256)), dim3(256), 0, s, nodes, n, f->B, f->n_ent, f->BW,
+                       f->bitsT[0], f->counters);
+    RG_LAUNCH_CHECK();
+  }
+  if (build_level(f, s)) return 1;
+  RG_HIP(hipMemcpyAsync(&f->counters[4], &f->counters[0], 4, hipMemcpyDeviceToDevice, s));
+  f->n_nodes[0] = n;   // duplicates or out-of-range ids are reported by the next expand
+  return 0;
+}
+
+int rg_frontier_expand(rg_frontier* f, const rg_graph* g, int64_t* counts_host, void* stream) {
+  RG_CHECK(f && g, "rg_frontier_expand: NULL argument");
+  RG_CHECK(f->level >= 0, "rg_frontier_expand: call rg_frontier_reset first");
+  RG_CHECK(g->n_ent == f->n_ent, "rg_frontier_expand: graph has %d entities, frontier %d", g->n_ent, f->n_ent);
+  hipStream_t s = (hipStream_t)stream;
+  const uint32_t* oldT = f->bitsT[f->tcur];
+  uint32_t* newT = f->bitsT[f->tcur ^ 1];
+  int WL = 1;
+  while (WL < f->BW && WL < 64) WL <<= 1;
+  RG_HIP(hipMemsetAsync(&f->counters[2], 0, 8, s));
+  hipLaunchKernelGGL(count_edges_kernel, dim3(rg::ceil_div((int64_t)f->n_ent * f->BW, 256)), dim3(256), 0, s, g->out_ptr,
+                     oldT, f->n_ent, f->BW, (unsigned long long*)&f->counters[2]);
+  RG_LAUNCH_CHECK();
+  hipLaunchKernelGGL(hop_or_kernel, dim3(rg::ceil_div(f->n_ent, 4)), dim3(256), 0, s, g->in_ptr, g->in_hr, oldT, newT,
+                     f->n_ent, f->BW, WL);
+  RG_LAUNCH_CHECK();
+  const int64_t n_old = f->n_nodes[f->level % f->n_levels];
+  f->tcur ^= 1;
+  f->level += 1;
+  if (build_level(f, s)) return 1;
+  RG_HIP(hipMemcpyAsync(f->counts_pinned, f->counters, 32, hipMemcpyDeviceToHost, s));
+  RG_HIP(hipStreamSynchronize(s));
+  const int32_t* c32 = (const int32_t*)f->counts_pinned;
+  RG_CHECK(c32[1] == 0, "rg_frontier_expand: a start node had batch or entity id out of range");
+  RG_CHECK(f->level != 1 || c32[4] == n_old, "rg_frontier_expand: %lld start nodes given but %d distinct (duplicates?)",
+           (long long)n_old, c32[4]);
+  const int64_t n_new = c32[0];
+  int64_t e;
+  memcpy(&e, &c32[2], 8);
+  f->n_nodes[f->level % f->n_levels] = n_new;
+  f->n_edges = e;
+  if (counts_host) { counts_host[0] = n_new; counts_host[1] = e; counts_host[2] = n_old; counts_host[3] = f->level; }
+  return 0;
+}
+
+int rg_frontier_nodes(const rg_frontier* f, int32_t* nodes, int32_t* prev_idx, int32_t* old_new, void* stream) {
+  RG_CHECK(f && f->level >= 0, "rg_frontier_nodes: frontier not initialised");
+  hipStream_t s = (hipStream_t)stream;
+  const int2* bm_old = f->level > 0 ? f->bm_of(f->level - 1) : nullptr;
+  RG_CHECK(!(old_new && !bm_old), "rg_frontier_nodes: level 0 has no previous level");
+  const int64_t nw = (int64_t)f->B * f->W;
+  hipLaunchKernelGGL(emit_nodes_kernel, dim3(rg::ceil_div(nw, 256)), dim3(256), 0, s, f->bm_of(f->level), bm_old, f->B, f->W,
+                     nodes, prev_idx, old_new);
+  RG_LAUNCH_CHECK();
+  return 0;
+}
+
+size_t rg_frontier_edges_scratch_bytes(int64_t n_new) {
+  return rg::align_up((size_t)(n_new + 1) * 4, 256) + rg::scan_scratch_elems(n_new) * 4 + 256;
+}
+
+int rg_frontier_edges(const rg_frontier* f, const rg_graph* g, int32_t level, const int32_t* nodes_new, int64_t n_new,
+                      int32_t* edges, int32_t* row_ptr, void* scratch, void* stream) {
+  RG_CHECK(f && g && nodes_new && row_ptr && scratch, "rg_frontier_edges: NULL argument");
+  RG_CHECK(level >= 1 && level <= f->level && level > f->level - f->n_levels + 1,
+           "rg_frontier_edges: level %d not resident (current %d, %d kept)", level, f->level, f->n_levels);
+  RG_CHECK(n_new == f->n_nodes[level % f->n_levels], "rg_frontier_edges: n_new=%lld but level %d has %lld nodes",
+           (long long)n_new, level, (long long)f->n_nodes[level % f->n_levels]);
+  hipStream_t s = (hipStream_t)stream;
+  uint32_t* deg = (uint32_t*)scratch;
+  int32_t* scan_scr = (int32_t*)((char*)scratch + rg::align_up((size_t)(n_new + 1) * 4, 256));
+  int32_t* total = scan_scr;          // first element; scan scratch proper starts after
+  const int2* bm_old = f->bm_of(level - 1);
+  if (n_new == 0) { RG_HIP(hipMemsetAsync(row_ptr, 0, 4, s)); return 0; }
+  hipLaunchKernelGGL(edge_count_kernel, dim3(rg::ceil_div(n_new, 256)), dim3(256), 0, s, nodes_new, n_new, g->in_ptr,
+                     g->in_hr, bm_old, f->W, deg);
+  RG_LAUNCH_CHECK();
+  if (rg::scan_exclusive(deg, row_ptr, n_new, false, total, scan_scr + 64, s)) return 1;
+  hipLaunchKernelGGL(set_last_kernel, dim3(1), dim3(1), 0, s, row_ptr, n_new, total);
+  RG_LAUNCH_CHECK();
+  if (edges) {
+    hipLaunchKernelGGL(edge_fill_kernel, dim3(rg::ceil_div(n_new, 256)), dim3(256), 0, s, nodes_new, n_new, g->in_ptr,
+                       g->in_hr, bm_old, f->W, row_ptr, edges);
+    RG_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+}  // extern "C"

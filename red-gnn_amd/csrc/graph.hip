@@ -1,0 +1,225 @@
+// Graph build + error plumbing + device scan.
+// Replaces Static/transductive/load_data.py:69-81 (double_triple, load_graph): the KG with
+// inverse and identity rows, held on the device as CSR-by-head and CSR-by-tail.
+#include <stdarg.h>
+#include <string.h>
+
+#include <vector>
+
+#include "common.h"
+
+namespace rg {
+
+static thread_local std::string g_err;
+
+void set_error(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+}
+
+// ------------------------------------------------------------------------------------------
+// Exclusive scan: reduce-then-scan, 256 threads x 8 items per block, recursive on block sums.
+// ------------------------------------------------------------------------------------------
+constexpr int SCAN_T = 256;
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_TILE = SCAN_T * SCAN_ITEMS;
+
+template <bool POPC>
+__device__ __forceinline__ int32_t scan_load(const uint32_t* in, int64_t i, int64_t n) {
+  if (i >= n) return 0;
+  uint32_t v = in[i];
+  return POPC ? __popc(v) : (int32_t)v;
+}
+
+__device__ __forceinline__ int32_t wave_incl_scan(int32_t v) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int32_t t = __shfl_up(v, o, 64);
+    if (lane >= o) v += t;
+  }
+  return v;
+}
+
+// block-wide exclusive scan of one value per thread; returns exclusive prefix, *block_total valid in all threads
+__device__ __forceinline__ int32_t block_excl_scan(int32_t v, int32_t* block_total) {
+  __shared__ int32_t wsum[SCAN_T / 64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int32_t inc = wave_incl_scan(v);
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  int32_t base = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_T / 64; ++i) {
+    int32_t x = wsum[i];
+    if (i < w) base += x;
+    tot += x;
+  }
+  __syncthreads();
+  *block_total = tot;
+  return base + inc - v;
+}
+
+template <bool POPC>
+__global__ __launch_bounds__(SCAN_T) void scan_reduce_kernel(const uint32_t* in, int64_t n, int32_t* sums) {
+  const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+  int32_t acc = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) acc += scan_load<POPC>(in, base + i, n);
+  int32_t tot;
+  block_excl_scan(acc, &tot);
+  if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+
+// offsets == nullptr: single-block scan (n <= SCAN_TILE), writes *total.
+template <bool POPC>
+__global__ __launch_bounds__(SCAN_T) void scan_apply_kernel(const uint32_t* in, int32_t* out, int64_t n,
+                                                            const int32_t* offsets, int32_t* total) {
+  const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+  int32_t v[SCAN_ITEMS];
+  int32_t acc = 0;
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) {
+    v[i] = scan_load<POPC>(in, base + i, n);
+    acc += v[i];
+  }
+  int32_t tot;
+  int32_t ex = block_excl_scan(acc, &tot);
+  if (offsets) ex += offsets[blockIdx.x];
+#pragma unroll
+  for (int i = 0; i < SCAN_ITEMS; ++i) {
+    if (base + i < n) out[base + i] = ex;
+    ex += v[i];
+  }
+  if (!offsets && total && threadIdx.x == 0) *total = tot;
+}
+
+size_t scan_scratch_elems(int64_t n) {
+  size_t tot = 0;
+  while (n > SCAN_TILE) {
+    n = ceil_div(n, SCAN_TILE);
+    tot += align_up((size_t)n, 64) * 2;  // sums + scanned sums per level
+  }
+  return tot + 64;
+}
+
+int scan_exclusive(const uint32_t* in, int32_t* out, int64_t n, bool popc, int32_t* total_dev,
+                   int32_t* scratch, hipStream_t s) {
+  if (n <= 0) {
+    if (total_dev) RG_HIP(hipMemsetAsync(total_dev, 0, sizeof(int32_t), s));
+    return 0;
+  }
+  const int64_t nb = ceil_div(n, SCAN_TILE);
+  if (nb == 1) {
+    if (popc)
+      hipLaunchKernelGGL(scan_apply_kernel<true>, dim3(1), dim3(SCAN_T), 0, s, in, out, n, nullptr, total_dev);
+    else
+      hipLaunchKernelGGL(scan_apply_kernel<false>, dim3(1), dim3(SCAN_T), 0, s, in, out, n, nullptr, total_dev);
+    RG_LAUNCH_CHECK();
+    return 0;
+  }
+  int32_t* sums = scratch;
+  int32_t* sums_scanned = scratch + align_up((size_t)nb, 64);
+  int32_t* next = sums_scanned + align_up((size_t)nb, 64);
+  if (popc)
+    hipLaunchKernelGGL(scan_reduce_kernel<true>, dim3(nb), dim3(SCAN_T), 0, s, in, n, sums);
+  else
+    hipLaunchKernelGGL(scan_reduce_kernel<false>, dim3(nb), dim3(SCAN_T), 0, s, in, n, sums);
+  RG_LAUNCH_CHECK();
+  if (scan_exclusive((const uint32_t*)sums, sums_scanned, nb, false, total_dev, next, s)) return 1;
+  if (popc)
+    hipLaunchKernelGGL(scan_apply_kernel<true>, dim3(nb), dim3(SCAN_T), 0, s, in, out, n, sums_scanned, nullptr);
+  else
+    hipLaunchKernelGGL(scan_apply_kernel<false>, dim3(nb), dim3(SCAN_T), 0, s, in, out, n, sums_scanned, nullptr);
+  RG_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace rg
+
+extern "C" {
+
+const char* rg_last_error(void) { return rg::g_err.c_str(); }
+int rg_version(void) { return 1; }
+
+int rg_graph_create(int32_t n_ent, int32_t n_rel, const int32_t* triples, int64_t n, int add_inverse,
+                    rg_graph** out) {
+  RG_CHECK(out != nullptr, "rg_graph_create: out is NULL");
+  *out = nullptr;
+  RG_CHECK(n_ent > 0 && n_rel > 0, "rg_graph_create: n_ent=%d n_rel=%d must be positive", n_ent, n_rel);
+  RG_CHECK(n >= 0 && (n == 0 || triples != nullptr), "rg_graph_create: bad triples (n=%lld)", (long long)n);
+  const int64_t n_fact = (add_inverse ? 2 * n : n) + n_ent;
+  RG_CHECK(n_fact < (int64_t)1 << 31, "rg_graph_create: %lld fact rows do not fit int32", (long long)n_fact);
+  // rows in the reference's order (load_data.py:69-80): triples, inverses, identity
+  std::vector<int32_t> H(n_fact), R(n_fact), T(n_fact);
+  const int32_t max_rel = add_inverse ? n_rel : 2 * n_rel;
+  for (int64_t i = 0; i < n; ++i) {
+    const int32_t h = triples[3 * i], r = triples[3 * i + 1], t = triples[3 * i + 2];
+    RG_CHECK(h >= 0 && h < n_ent && t >= 0 && t < n_ent && r >= 0 && r < max_rel,
+             "rg_graph_create: triple %lld = (%d,%d,%d) out of range", (long long)i, h, r, t);
+    H[i] = h; R[i] = r; T[i] = t;
+    if (add_inverse) { H[n + i] = t; R[n + i] = r + n_rel; T[n + i] = h; }
+  }
+  const int64_t id0 = n_fact - n_ent;
+  for (int32_t e = 0; e < n_ent; ++e) { H[id0 + e] = e; R[id0 + e] = 2 * n_rel; T[id0 + e] = e; }
+
+  std::vector<int32_t> out_ptr(n_ent + 1, 0), in_ptr(n_ent + 1, 0);
+  for (int64_t i = 0; i < n_fact; ++i) { out_ptr[H[i] + 1]++; in_ptr[T[i] + 1]++; }
+  int32_t max_in = 0, max_out = 0;
+  for (int32_t e = 0; e < n_ent; ++e) {
+    max_out = out_ptr[e + 1] > max_out ? out_ptr[e + 1] : max_out;
+    max_in = in_ptr[e + 1] > max_in ? in_ptr[e + 1] : max_in;
+    out_ptr[e + 1] += out_ptr[e];
+    in_ptr[e + 1] += in_ptr[e];
+  }
+  std::vector<int2> out_rt(n_fact), in_hr(n_fact);
+  {
+    std::vector<int32_t> po(out_ptr.begin(), out_ptr.end() - 1), pi(in_ptr.begin(), in_ptr.end() - 1);
+    for (int64_t i = 0; i < n_fact; ++i) {  // stable: fact-row order inside each CSR row
+      out_rt[po[H[i]]++] = make_int2(R[i], T[i]);
+      in_hr[pi[T[i]]++] = make_int2(H[i], R[i]);
+    }
+  }
+  rg_graph* g = new rg_graph();
+  g->n_ent = n_ent; g->n_rel = n_rel; g->n_fact = n_fact; g->max_in_deg = max_in; g->max_out_deg = max_out;
+  auto fail = [&]() { rg_graph_destroy(g); return 1; };
+#define RG_HIP_G(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { rg::set_error("%s failed: %s", #expr, hipGetErrorString(e_)); return fail(); } } while (0)
+  RG_HIP_G(hipMalloc(&g->out_ptr, (n_ent + 1) * sizeof(int32_t)));
+  RG_HIP_G(hipMalloc(&g->in_ptr, (n_ent + 1) * sizeof(int32_t)));
+  RG_HIP_G(hipMalloc(&g->out_rt, n_fact * sizeof(int2)));
+  RG_HIP_G(hipMalloc(&g->in_hr, n_fact * sizeof(int2)));
+  RG_HIP_G(hipMemcpy(g->out_ptr, out_ptr.data(), (n_ent + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+  RG_HIP_G(hipMemcpy(g->in_ptr, in_ptr.data(), (n_ent + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+  RG_HIP_G(hipMemcpy(g->out_rt, out_rt.data(), n_fact * sizeof(int2), hipMemcpyHostToDevice));
+  RG_HIP_G(hipMemcpy(g->in_hr, in_hr.data(), n_fact * sizeof(int2), hipMemcpyHostToDevice));
+#undef RG_HIP_G
+  *out = g;
+  return 0;
+}
+
+int rg_graph_destroy(rg_graph* g) {
+  if (!g) return 0;
+  if (g->out_ptr) (void)hipFree(g->out_ptr);
+  if (g->in_ptr) (void)hipFree(g->in_ptr);
+  if (g->out_rt) (void)hipFree(g->out_rt);
+  if (g->in_hr) (void)hipFree(g->in_hr);
+  delete g;
+  return 0;
+}
+
+int64_t rg_graph_n_fact(const rg_graph* g) { return g ? g->n_fact : -1; }
+
+int rg_graph_export(const rg_graph* g, int32_t* out_ptr, int32_t* out_rt, int32_t* in_ptr, int32_t* in_hr) {
+  RG_CHECK(g != nullptr, "rg_graph_export: graph is NULL");
+  if (out_ptr) RG_HIP(hipMemcpy(out_ptr, g->out_ptr, (g->n_ent + 1) * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (in_ptr) RG_HIP(hipMemcpy(in_ptr, g->in_ptr, (g->n_ent + 1) * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (out_rt) RG_HIP(hipMemcpy(out_rt, g->out_rt, g->n_fact * sizeof(int2), hipMemcpyDeviceToHost));
+  if (in_hr) RG_HIP(hipMemcpy(in_hr, g->in_hr, g->n_fact * sizeof(int2), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+}  // extern "C"

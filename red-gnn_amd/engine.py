@@ -1,0 +1,182 @@
+"""Thin host objects over the C-ABI handles: ``Graph`` (rg_graph) and ``Frontier`` (rg_frontier).
+
+PyTorch is used here for device memory and the current HIP stream only; every computation
+below is a call into libredgnn.so.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _require_gpu(device):
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise _lib.NativeError("red_gnn_amd runs on an MI355X (device 'cuda'); got device %r. "
+                               "There is no CPU path in the product — the CPU restatement lives in oracle/ for tests only."
+                               % (device,))
+    return device
+
+
+class Graph:
+    """Device-resident KG (inverse + identity rows added, CSR by head and by tail).
+    Replaces load_data.py:69-81 (double_triple + load_graph)."""
+
+    def __init__(self, n_ent, n_rel, triples, add_inverse=True, device="cuda"):
+        self.device = _require_gpu(device)
+        trip = np.ascontiguousarray(np.asarray(triples, dtype=np.int32).reshape(-1, 3))
+        self.n_ent, self.n_rel = int(n_ent), int(n_rel)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().rg_graph_create(self.n_ent, self.n_rel, _lib.ptr(trip), len(trip),
+                                                  1 if add_inverse else 0, C.byref(h)))
+        self.handle = h
+        self.n_fact = int(_lib.lib().rg_graph_n_fact(h))
+
+    def export(self):
+        """(out_ptr, out_rel_tail[n_fact,2], in_ptr, in_head_rel[n_fact,2]) as numpy — for tests."""
+        op = np.empty(self.n_ent + 1, np.int32)
+        ip = np.empty(self.n_ent + 1, np.int32)
+        ort = np.empty((self.n_fact, 2), np.int32)
+        ihr = np.empty((self.n_fact, 2), np.int32)
+        _lib.check(_lib.lib().rg_graph_export(self.handle, _lib.ptr(op), _lib.ptr(ort), _lib.ptr(ip), _lib.ptr(ihr)))
+        return op, ort, ip, ihr
+
+    def close(self):
+        if getattr(self, "handle", None) is not None and _lib._lib is not None:
+            _lib.lib().rg_graph_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Frontier:
+    """Per-batch visited-set state (levels of (batch, entity) node sets) in a torch-owned workspace.
+    Replaces the state threaded through RED_GNN_trans.forward / DataLoader.get_neighbors
+    (models.py:73-78, load_data.py:106-131)."""
+
+    def __init__(self, n_ent, batch, n_levels=2, device="cuda"):
+        self.device = _require_gpu(device)
+        L = _lib.lib()
+        self.n_ent, self.batch, self.n_levels = int(n_ent), int(batch), int(n_levels)
+        nbytes = L.rg_frontier_workspace_bytes(self.n_ent, self.batch, self.n_levels)
+        if nbytes == 0:
+            raise _lib.NativeError("bad frontier shape n_ent=%d batch=%d n_levels=%d" % (n_ent, batch, n_levels))
+        self.workspace = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+        base = self.workspace.data_ptr()
+        aligned = (base + 255) // 256 * 256
+        h = C.c_void_p()
+        _lib.check(L.rg_frontier_create(self.n_ent, self.batch, self.n_levels, C.c_void_p(aligned), nbytes, C.byref(h)))
+        self.handle = h
+        self._counts = (C.c_int64 * 4)()
+        self.level = -1
+        self.n_new = self.n_old = self.n_edges = 0
+
+    def reset(self, q_sub):
+        """Level 0 = {(b, q_sub[b])} (models.py:73).  q_sub: int32 device tensor [batch]."""
+        assert q_sub.dtype == torch.int32 and q_sub.is_cuda and q_sub.numel() == self.batch
+        _lib.check(_lib.lib().rg_frontier_reset(self.handle, _lib.ptr(q_sub), _lib.stream_ptr()))
+        self.level, self.n_new, self.n_old, self.n_edges = 0, self.batch, 0, 0
+
+    def reset_nodes(self, nodes):
+        """Level 0 = an arbitrary node set, int32 device tensor [n,2] (batch, entity)."""
+        assert nodes.dtype == torch.int32 and nodes.is_cuda and nodes.dim() == 2 and nodes.shape[1] == 2
+        nodes = nodes.contiguous()
+        _lib.check(_lib.lib().rg_frontier_reset_nodes(self.handle, _lib.ptr(nodes), nodes.shape[0], _lib.stream_ptr()))
+        self.level, self.n_new, self.n_old, self.n_edges = 0, nodes.shape[0], 0, 0
+
+    def expand(self, graph):
+        """One hop.  Returns (n_new, n_edges, n_old); synchronises the stream once."""
+        _lib.check(_lib.lib().rg_frontier_expand(self.handle, graph.handle, self._counts, _lib.stream_ptr()))
+        self.n_new, self.n_edges, self.n_old, self.level = (int(self._counts[i]) for i in range(4))
+        return self.n_new, self.n_edges, self.n_old
+
+    def nodes(self, want_prev=True, want_old_new=True):
+        """(nodes int32 [n_new,2] sorted, prev_idx int32 [n_new] or None, old_nodes_new_idx int32 [n_old] or None)."""
+        nodes = torch.empty((self.n_new, 2), dtype=torch.int32, device=self.device)
+        prev = torch.empty(self.n_new, dtype=torch.int32, device=self.device) if want_prev else None
+        old_new = (torch.empty(self.n_old, dtype=torch.int32, device=self.device)
+                   if (want_old_new and self.level > 0) else None)
+        _lib.check(_lib.lib().rg_frontier_nodes(self.handle, _lib.ptr(nodes), _lib.ptr(prev), _lib.ptr(old_new),
+                                                _lib.stream_ptr()))
+        return nodes, prev, old_new
+
+    def edges(self, graph, nodes_new, level=None):
+        """Materialised (batch, head, rel, tail, old_idx, new_idx) int32 [E,6] + row_ptr [n_new+1]
+        of hop level-1 -> level (destination-segmented)."""
+        level = self.level if level is None else level
+        n_new = nodes_new.shape[0]
+        L = _lib.lib()
+        scratch = torch.empty(L.rg_frontier_edges_scratch_bytes(n_new), dtype=torch.uint8, device=self.device)
+        row_ptr = torch.empty(n_new + 1, dtype=torch.int32, device=self.device)
+        # pass 1: counts only -> E
+        _lib.check(L.rg_frontier_edges(self.handle, graph.handle, level, _lib.ptr(nodes_new), n_new, None,
+                                       _lib.ptr(row_ptr), _lib.ptr(scratch), _lib.stream_ptr()))
+        n_e = int(row_ptr[-1].item())
+        edges = torch.empty((n_e, 6), dtype=torch.int32, device=self.device)
+        _lib.check(L.rg_frontier_edges(self.handle, graph.handle, level, _lib.ptr(nodes_new), n_new, _lib.ptr(edges),
+                                       _lib.ptr(row_ptr), _lib.ptr(scratch), _lib.stream_ptr()))
+        return edges, row_ptr
+
+    def close(self):
+        if getattr(self, "handle", None) is not None and _lib._lib is not None:
+            _lib.lib().rg_frontier_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def layer_fwd(frontier, graph, level, nodes_new, hidden, rela, d, a_s, a_r, a_q, w_alpha, b_alpha, attn_dim):
+    """agg [n_new, ld] = fused message passing of hop level-1 -> level (rg_layer_fwd)."""
+    ld, ap = hidden.shape[1], a_s.shape[1]
+    for t in (hidden, rela, a_s, a_r, a_q, w_alpha, b_alpha):
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+    assert rela.shape[1] == ld and a_r.shape[1] == ap and a_q.shape[1] == ap
+    n_new = nodes_new.shape[0]
+    agg = torch.empty((n_new, ld), dtype=torch.float32, device=hidden.device)
+    _lib.check(_lib.lib().rg_layer_fwd(frontier.handle, graph.handle, level, _lib.ptr(nodes_new), n_new,
+                                       _lib.ptr(hidden), _lib.ptr(rela), d, ld, _lib.ptr(a_s), _lib.ptr(a_r),
+                                       _lib.ptr(a_q), ap, _lib.ptr(w_alpha), _lib.ptr(b_alpha), attn_dim,
+                                       _lib.ptr(agg), _lib.stream_ptr()))
+    return agg
+
+
+def layer_bwd(frontier, graph, level, nodes_old, hidden, rela, d, a_s, a_r, a_q, w_alpha, b_alpha, attn_dim, grad_agg):
+    """Adjoint of layer_fwd (rg_layer_bwd).  Returns grads of (hidden, rela, a_s, a_r, a_q, w_alpha, b_alpha)."""
+    ld, ap = hidden.shape[1], a_s.shape[1]
+    grad_agg = grad_agg.contiguous()
+    n_old = nodes_old.shape[0]
+    dev = hidden.device
+    g_h = torch.empty_like(hidden)
+    g_as = torch.empty_like(a_s)
+    g_rela = torch.zeros_like(rela)
+    g_ar = torch.zeros_like(a_r)
+    g_aq = torch.zeros_like(a_q)
+    g_w = torch.zeros(attn_dim, dtype=torch.float32, device=dev)
+    g_b = torch.zeros(1, dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib().rg_layer_bwd(frontier.handle, graph.handle, level, _lib.ptr(nodes_old), n_old,
+                                       _lib.ptr(hidden), _lib.ptr(rela), d, ld, _lib.ptr(a_s), _lib.ptr(a_r),
+                                       _lib.ptr(a_q), ap, _lib.ptr(w_alpha), _lib.ptr(b_alpha), attn_dim,
+                                       _lib.ptr(grad_agg), _lib.ptr(g_h), _lib.ptr(g_rela), _lib.ptr(g_as),
+                                       _lib.ptr(g_ar), _lib.ptr(g_aq), _lib.ptr(g_w), _lib.ptr(g_b), _lib.stream_ptr()))
+    return g_h, g_rela, g_as, g_ar, g_aq, g_w, g_b
+
+
+def rank(scores, ans_ptr, ans_idx, filt_ptr, filt_idx):
+    """Filtered ranks (rg_rank) of every answer, fp32 [len(ans_idx)] in (query, answer) order."""
+    assert scores.is_cuda and scores.dtype == torch.float32 and scores.is_contiguous()
+    B, n_ent = scores.shape
+    out = torch.empty(ans_idx.numel(), dtype=torch.float32, device=scores.device)
+    _lib.check(_lib.lib().rg_rank(_lib.ptr(scores), B, n_ent, _lib.ptr(ans_ptr), _lib.ptr(ans_idx),
+                                  _lib.ptr(filt_ptr), _lib.ptr(filt_idx), _lib.ptr(out), _lib.stream_ptr()))
+    return out

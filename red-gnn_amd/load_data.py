@@ -1,0 +1,166 @@
+"""DataLoader with the reference's interface (Static/transductive/load_data.py:7-164), backed by
+device-resident graphs and the HIP frontier expansion.
+
+Same constructor argument (``task_dir`` with entities.txt / relations.txt / facts.txt / train.txt /
+valid.txt / test.txt), same attributes the trainer reads (``n_ent, n_rel, n_train, n_valid, n_test,
+filters, valid_q/valid_a, test_q/test_a, train_data``) and the same methods (``get_neighbors``,
+``get_batch``, ``shuffle_train``).  Differences, all internal: the KG is int32 on the device instead
+of a float64 numpy array + scipy CSR (load_data.py:77-81), and ``get_neighbors`` runs on the GPU.
+``ids=`` builds the loader from pre-parsed id arrays (fixtures, synthetic KGs) instead of text.
+"""
+import os
+from collections import defaultdict
+
+import numpy as np
+import torch
+
+from .engine import Frontier, Graph
+
+
+class DataLoader:
+    def __init__(self, task_dir=None, ids=None, device="cuda", verbose=True):
+        self.task_dir = task_dir
+        self.device = torch.device(device)
+        self.filters = defaultdict(set)
+        if ids is None:
+            self._read_text(task_dir)
+        else:
+            self.n_ent, self.n_rel = int(ids["n_ent"]), int(ids["n_rel"])
+            self.fact_triple = self._register(ids["facts"])
+            self.train_triple = self._register(ids["train"])
+            self.valid_triple = self._register(ids["valid"])
+            self.test_triple = self._register(ids["test"])
+
+        # add inverse (load_data.py:37-41)
+        self.fact_data = self.double_triple(self.fact_triple)
+        self.train_data = self.double_triple(self.train_triple)
+        self.valid_data = self.double_triple(self.valid_triple)
+        self.test_data = self.double_triple(self.test_triple)
+
+        self.graph = self.tgraph = None
+        self.load_graph(self.fact_triple)                                               # :43
+        self.load_test_graph(np.concatenate([self.fact_triple, self.train_triple], 0))  # :44
+
+        self.valid_q, self.valid_a = self.load_query(self.valid_data)
+        self.test_q, self.test_a = self.load_query(self.test_data)
+        self.n_train, self.n_valid, self.n_test = len(self.train_data), len(self.valid_q), len(self.test_q)
+        self.filters = {k: sorted(v) for k, v in self.filters.items()}
+        self._frontiers = {}
+        if verbose:
+            print("n_train:", self.n_train, "n_valid:", self.n_valid, "n_test:", self.n_test)
+
+    # ---- parsing (load_data.py:11-25, 58-67) ----------------------------------------------------
+    def _read_text(self, task_dir):
+        def ids_of(fname):
+            with open(os.path.join(task_dir, fname)) as f:
+                return {line.strip(): i for i, line in enumerate(f)}
+        self.entity2id = ids_of("entities.txt")
+        self.relation2id = ids_of("relations.txt")
+        self.n_ent, self.n_rel = len(self.entity2id), len(self.relation2id)
+        self.fact_triple = self.read_triples("facts.txt")
+        self.train_triple = self.read_triples("train.txt")
+        self.valid_triple = self.read_triples("valid.txt")
+        self.test_triple = self.read_triples("test.txt")
+
+    def read_triples(self, filename):
+        rows = []
+        with open(os.path.join(self.task_dir, filename)) as f:
+            for line in f:
+                h, r, t = line.strip().split()
+                rows.append((self.entity2id[h], self.relation2id[r], self.entity2id[t]))
+        return self._register(np.array(rows, dtype=np.int64).reshape(-1, 3))
+
+    def _register(self, triples):
+        """Every known (h,r,t) of any split goes into the filter sets (load_data.py:65-66)."""
+        triples = np.asarray(triples, dtype=np.int64).reshape(-1, 3)
+        for h, r, t in triples.tolist():
+            self.filters[(h, r)].add(t)
+            self.filters[(t, r + self.n_rel)].add(h)
+        return triples
+
+    def double_triple(self, triples):
+        """load_data.py:69-74."""
+        triples = np.asarray(triples, dtype=np.int64).reshape(-1, 3)
+        inv = np.stack([triples[:, 2], triples[:, 1] + self.n_rel, triples[:, 0]], 1)
+        return np.concatenate([triples, inv], 0)
+
+    # ---- graphs (load_data.py:76-89): inverse + identity rows are added by rg_graph_create -----------
+    def load_graph(self, base_triples):
+        if self.graph is not None:
+            self.graph.close()
+        self.graph = Graph(self.n_ent, self.n_rel, base_triples, add_inverse=True, device=self.device)
+        self.n_fact = self.graph.n_fact
+
+    def load_test_graph(self, base_triples):
+        if self.tgraph is not None:
+            self.tgraph.close()
+        self.tgraph = Graph(self.n_ent, self.n_rel, base_triples, add_inverse=True, device=self.device)
+        self.tn_fact = self.tgraph.n_fact
+
+    def graph_for(self, mode):
+        """load_data.py:107-112: 'train' walks the fact graph, anything else facts + train."""
+        return self.graph if mode == "train" else self.tgraph
+
+    def load_query(self, triples):
+        """load_data.py:91-104: group by (h, r), queries sorted by (h, r)."""
+        by_hr = defaultdict(list)
+        for h, r, t in sorted(map(tuple, np.asarray(triples).tolist()), key=lambda x: (x[0], x[1])):
+            by_hr[(h, r)].append(t)
+        queries = list(by_hr.keys())
+        answers = [np.array(by_hr[k]) for k in queries]
+        return queries, answers
+
+    # ---- frontier expansion (load_data.py:106-131) ---------------------------------------------------
+    def get_neighbors(self, nodes, mode="train"):
+        """Same contract as the reference: nodes [N,2] (batch_idx, entity) ->
+        (tail_nodes LongTensor [N',2] sorted, sampled_edges LongTensor [E,6], old_nodes_new_idx LongTensor [N]),
+        on the device.  Edges come destination-segmented (the reference's order is fact-row major)."""
+        nodes_t = torch.as_tensor(np.asarray(nodes) if not torch.is_tensor(nodes) else nodes)
+        nodes_t = nodes_t.to(device=self.device, dtype=torch.int32).contiguous()
+        n_batch = int(nodes_t[:, 0].max().item()) + 1 if nodes_t.numel() else 1
+        graph = self.graph_for(mode)
+        key = ("gn", n_batch)
+        fr = self._frontiers.get(key)
+        if fr is None:
+            fr = self._frontiers[key] = Frontier(self.n_ent, n_batch, 2, self.device)
+        fr.reset_nodes(nodes_t)
+        fr.expand(graph)
+        tail_nodes, _, old_new = fr.nodes(want_prev=False)
+        edges, _ = fr.edges(graph, tail_nodes)
+        return tail_nodes.long(), edges.long(), old_new.long()
+
+    # ---- batches (load_data.py:133-150) --------------------------------------------------------------
+    def get_batch(self, batch_idx, steps=2, data="train"):
+        if data == "train":
+            return self.train_data[batch_idx]
+        query, answer = (self.valid_q, self.valid_a) if data == "valid" else (self.test_q, self.test_a)
+        batch_idx = np.asarray(batch_idx)
+        subs = np.array([query[i][0] for i in batch_idx])
+        rels = np.array([query[i][1] for i in batch_idx])
+        objs = np.zeros((len(batch_idx), self.n_ent))
+        for i, q in enumerate(batch_idx):
+            objs[i][answer[q]] = 1
+        return subs, rels, objs
+
+    def get_batch_csr(self, batch_idx, data="valid"):
+        """The same batch as device CSR lists for the GPU ranker: (subs, rels, ans_ptr, ans_idx, filt_ptr, filt_idx)."""
+        query, answer = (self.valid_q, self.valid_a) if data == "valid" else (self.test_q, self.test_a)
+        subs = np.array([query[i][0] for i in batch_idx])
+        rels = np.array([query[i][1] for i in batch_idx])
+        ans = [np.sort(np.asarray(answer[i])) for i in batch_idx]       # np.nonzero order of base_model.py / utils.py:12-13
+        fil = [np.asarray(self.filters[(int(s), int(r))]) for s, r in zip(subs, rels)]
+        to_dev = lambda a: torch.as_tensor(a, dtype=torch.int32, device=self.device)
+        ptr = lambda lists: np.concatenate([[0], np.cumsum([len(x) for x in lists])])
+        cat = lambda lists: np.concatenate(lists) if len(lists) else np.zeros(0, np.int64)
+        return subs, rels, to_dev(ptr(ans)), to_dev(cat(ans)), to_dev(ptr(fil)), to_dev(cat(fil))
+
+    def shuffle_train(self):
+        """load_data.py:152-164: re-split facts/train 3:1 and rebuild the training graph."""
+        all_triple = np.concatenate([self.fact_triple, self.train_triple], axis=0)
+        n_all = len(all_triple)
+        all_triple = all_triple[np.random.permutation(n_all)]
+        facts, train = all_triple[:n_all * 3 // 4], all_triple[n_all * 3 // 4:]
+        self.fact_data = self.double_triple(facts)
+        self.train_data = self.double_triple(train)
+        self.n_train = len(self.train_data)
+        self.load_graph(facts)

@@ -1,0 +1,140 @@
+"""RED_GNN_trans / GNNLayer with the reference's nn.Module API and state-dict names
+(Static/transductive/models.py:5-89), running the hot path in hand-written HIP kernels.
+
+    model = RED_GNN_trans(params, loader).cuda()
+    scores = model(subs, rels, mode='train'|'valid'|'test')      # fp32 [B, n_ent], 0 at unvisited entities
+
+What is different inside (nothing is different outside):
+  * no host round trip per layer: the frontier lives on the device as bitmaps (engine.Frontier),
+    one 32-byte read-back per hop returns the node/edge counts;
+  * models.py:29-39 (gathers, attention, torch_scatter sum) is one fused kernel, rg_layer_fwd, and
+    its adjoint rg_layer_bwd; the three attention Linear layers are hoisted to per-node /
+    per-relation / per-query projections (exact re-association);
+  * dense algebra that is not on the E-proportional path (W_h, GRU cell, hoisted projections,
+    W_final) stays in torch on the device (rocBLAS / fused gru_cell), differentiable as usual.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import engine
+
+
+def _pad4(n):
+    return (n + 3) // 4 * 4
+
+
+class _Aggregate(torch.autograd.Function):
+    """agg = rg_layer_fwd(...);  backward = rg_layer_bwd(...)."""
+
+    @staticmethod
+    def forward(ctx, hidden, rela, a_s, a_r, a_q, w_alpha, b_alpha, frontier, graph, level, nodes_new, nodes_old, d, attn_dim):
+        hidden, rela, a_s, a_r, a_q = (t.contiguous() for t in (hidden, rela, a_s, a_r, a_q))
+        w_alpha, b_alpha = w_alpha.contiguous(), b_alpha.contiguous()
+        agg = engine.layer_fwd(frontier, graph, level, nodes_new, hidden, rela, d, a_s, a_r, a_q, w_alpha, b_alpha, attn_dim)
+        ctx.save_for_backward(hidden, rela, a_s, a_r, a_q, w_alpha, b_alpha, nodes_old)
+        ctx.misc = (frontier, graph, level, d, attn_dim)
+        return agg
+
+    @staticmethod
+    def backward(ctx, grad_agg):
+        hidden, rela, a_s, a_r, a_q, w_alpha, b_alpha, nodes_old = ctx.saved_tensors
+        frontier, graph, level, d, attn_dim = ctx.misc
+        g_h, g_rela, g_as, g_ar, g_aq, g_w, g_b = engine.layer_bwd(
+            frontier, graph, level, nodes_old, hidden, rela, d, a_s, a_r, a_q, w_alpha, b_alpha, attn_dim, grad_agg)
+        # dA_q[b] = sum of dA_s over the nodes of query b (nodes are sorted by batch)
+        g_aq.index_add_(0, nodes_old[:, 0].long(), g_as)
+        return g_h, g_rela, g_as, g_ar, g_aq, g_w.view_as(w_alpha), g_b.view_as(b_alpha), None, None, None, None, None, None, None
+
+
+class GNNLayer(nn.Module):
+    """Parameters exactly as models.py:14-21."""
+
+    def __init__(self, in_dim, out_dim, attn_dim, n_rel, act=lambda x: x):
+        super().__init__()
+        self.n_rel, self.in_dim, self.out_dim, self.attn_dim, self.act = n_rel, in_dim, out_dim, attn_dim, act
+        self.rela_embed = nn.Embedding(2 * n_rel + 1, in_dim)
+        self.Ws_attn = nn.Linear(in_dim, attn_dim, bias=False)
+        self.Wr_attn = nn.Linear(in_dim, attn_dim, bias=False)
+        self.Wqr_attn = nn.Linear(in_dim, attn_dim)
+        self.w_alpha = nn.Linear(attn_dim, 1)
+        self.W_h = nn.Linear(in_dim, out_dim, bias=False)
+
+    def aggregate(self, q_rel, hidden, frontier, graph, level, nodes_new, nodes_old):
+        """models.py:29-39 on the device; returns message_agg [n_new, in_dim]."""
+        d, a = self.in_dim, self.attn_dim
+        ld, ap = max(16, _pad4(d)), _pad4(a)
+        rela = self.rela_embed.weight
+        pad_rows = lambda w: F.pad(w, (0, 0, 0, ap - a)) if ap != a else w
+        a_s = F.linear(hidden, pad_rows(self.Ws_attn.weight))                                   # [n_old, ap]
+        a_r = F.linear(rela, pad_rows(self.Wr_attn.weight))                                     # [2R+1, ap]
+        a_q = F.linear(rela[q_rel], pad_rows(self.Wqr_attn.weight), F.pad(self.Wqr_attn.bias, (0, ap - a)))  # [B, ap]
+        if ld != d:
+            hidden, rela = F.pad(hidden, (0, ld - d)), F.pad(rela, (0, ld - d))
+        agg = _Aggregate.apply(hidden, rela, a_s, a_r, a_q, self.w_alpha.weight.reshape(-1), self.w_alpha.bias,
+                               frontier, graph, level, nodes_new, nodes_old, d, a)
+        return agg[:, :d] if ld != d else agg
+
+    def forward(self, q_sub, q_rel, hidden, frontier, graph, level, nodes_new, nodes_old):
+        return self.act(self.W_h(self.aggregate(q_rel, hidden, frontier, graph, level, nodes_new, nodes_old)))   # models.py:41
+
+
+class RED_GNN_trans(nn.Module):
+    def __init__(self, params, loader):
+        super().__init__()
+        self.n_layer, self.hidden_dim, self.attn_dim, self.n_rel = params.n_layer, params.hidden_dim, params.attn_dim, params.n_rel
+        self.loader = loader
+        acts = {"relu": nn.ReLU(), "tanh": torch.tanh, "idd": lambda x: x}
+        act = acts[params.act]
+        self.gnn_layers = nn.ModuleList(
+            [GNNLayer(self.hidden_dim, self.hidden_dim, self.attn_dim, self.n_rel, act=act) for _ in range(self.n_layer)])
+        self.dropout = nn.Dropout(params.dropout)
+        self.W_final = nn.Linear(self.hidden_dim, 1, bias=False)
+        self.gate = nn.GRU(self.hidden_dim, self.hidden_dim)     # parameters only; the single step runs as gru_cell
+        self._frontiers = {}
+        self.last_stats = None
+
+    def _frontier(self, batch, n_levels, device):
+        key = (batch, n_levels, str(device))
+        fr = self._frontiers.get(key)
+        if fr is None:
+            if len(self._frontiers) > 8:
+                self._frontiers.clear()
+            fr = self._frontiers[key] = engine.Frontier(self.loader.n_ent, batch, n_levels, device)
+        return fr
+
+    def forward(self, subs, rels, mode="train", trace=None):
+        device = self.W_final.weight.device
+        engine._require_gpu(device)
+        n = len(subs)
+        graph = self.loader.graph_for(mode)
+        q_sub = torch.as_tensor(np.asarray(subs), dtype=torch.int32).to(device)
+        q_rel = torch.as_tensor(np.asarray(rels), dtype=torch.int64).to(device)
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        fr = self._frontier(n, self.n_layer + 1 if need_grad else 2, device)
+        fr.reset(q_sub)
+
+        d = self.hidden_dim
+        h0 = torch.zeros((n, d), device=device)                                  # models.py:72
+        hidden = torch.zeros((n, d), device=device)                              # models.py:74
+        nodes_old = torch.stack([torch.arange(n, device=device, dtype=torch.int32), q_sub], 1)   # models.py:73
+        g = self.gate
+        n_edges = []
+        for i in range(self.n_layer):                                            # models.py:77
+            n_new, n_e, _ = fr.expand(graph)                                     # models.py:78 (on the device)
+            nodes, _, old_new = fr.nodes(want_prev=False)
+            n_edges.append(n_e)
+            hidden = self.gnn_layers[i](q_sub, q_rel, hidden, fr, graph, fr.level, nodes, nodes_old)   # models.py:80
+            h0 = torch.zeros((n_new, d), device=device).index_copy(0, old_new.long(), h0)           # models.py:81
+            hidden = self.dropout(hidden)                                        # models.py:82
+            hidden = torch.gru_cell(hidden, h0, g.weight_ih_l0, g.weight_hh_l0, g.bias_ih_l0, g.bias_hh_l0)   # models.py:83
+            h0 = hidden
+            if trace is not None:
+                trace.append(dict(nodes=nodes, old_nodes_new_idx=old_new, n_edges=n_e, hidden=hidden))
+            nodes_old = nodes
+        scores = self.W_final(hidden).squeeze(-1)                                # models.py:86
+        key = nodes_old[:, 0].long() * self.loader.n_ent + nodes_old[:, 1].long()
+        scores_all = torch.zeros(n * self.loader.n_ent, device=device).index_copy(0, key, scores)    # models.py:87-88
+        self.last_stats = dict(n_edges=n_edges, n_nodes=int(nodes_old.shape[0]))
+        return scores_all.view(n, self.loader.n_ent)

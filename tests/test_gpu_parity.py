@@ -1,0 +1,256 @@
+"""Parity of the HIP path (through the C-ABI, libredgnn.so) against the oracle and the golden
+fixtures generated from the reference.  Needs an MI355X: every test is marked ``gpu``.
+
+Bars: node sets, old_nodes_new_idx, edge multisets and ranks bit-exact; fp32 values within
+rtol 1e-4 of the reference's CPU results, with atol 1e-5 on scores and 5e-5 on hidden states
+(O(1) values built from fp32 sums of up to ~300 terms per destination over up to 5 layers; the
+reference's own sum order is unspecified, SURVEY.md §7 "Determinism / tolerance"), and
+rtol 2e-3 / atol 2e-5 on gradients (sums over every edge of the batch).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import redgnn_oracle as orc
+from tests import _util as U
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL, ATOL_H = 1e-4, 1e-5, 5e-5
+
+
+class P:
+    def __init__(self, n_layer, hidden_dim, attn_dim, n_rel, act, dropout=0.0):
+        self.n_layer, self.hidden_dim, self.attn_dim, self.n_rel, self.act, self.dropout = n_layer, hidden_dim, attn_dim, n_rel, act, dropout
+
+
+def make_model(fx, ids, train=False):
+    from red_gnn_amd.load_data import DataLoader
+    from red_gnn_amd.models import RED_GNN_trans
+    loader = DataLoader(ids=ids, verbose=False)
+    n_layer, d, a = (int(x) for x in fx["cfg"])
+    model = RED_GNN_trans(P(n_layer, d, a, loader.n_rel, str(fx["act"])), loader).cuda()
+    sd = {k: torch.tensor(v) for k, v in U.params_of(fx).items()}
+    missing, unexpected = model.load_state_dict(sd, strict=True)
+    model.train() if train else model.eval()
+    return loader, model
+
+
+def test_library_version_and_graph_export():
+    from red_gnn_amd import _lib
+    from red_gnn_amd.engine import Graph
+    assert _lib.lib().rg_version() >= 1
+    ids = U.load("tiny_fwd.npz")
+    n_ent, n_rel = int(ids["n_ent"]), int(ids["n_rel"])
+    base = np.concatenate([ids["facts"], ids["train"]], 0)
+    g = Graph(n_ent, n_rel, base)
+    og = orc.OracleGraph(orc.double_triple(base, n_rel), n_ent, n_rel)   # same fact-row order as rg_graph_create
+    assert g.n_fact == og.n_fact == U.oracle_graph(ids, "test").n_fact
+    op, ort, ip, ihr = g.export()
+    assert np.array_equal(op, og.head_ptr)
+    kg = og.KG[og.rows_by_head]                  # rows grouped by head, fact order inside
+    assert np.array_equal(ort, kg[:, [1, 2]])
+    order_t = np.argsort(og.KG[:, 2], kind="stable")
+    assert np.array_equal(ihr, og.KG[order_t][:, [0, 1]])
+    assert ip[-1] == og.n_fact
+
+
+@pytest.mark.parametrize("name,ids", [("tiny_fwd.npz", None), ("family_d64.npz", "family_ids.npz"), ("umls_d48.npz", "umls_ids.npz")])
+def test_get_neighbors_matches_oracle_every_hop(name, ids):
+    """DataLoader.get_neighbors (HIP) vs the oracle's restatement of load_data.py:106-131, hop by hop."""
+    from red_gnn_amd.load_data import DataLoader
+    fx = U.load(name)
+    ids = fx if ids is None else U.load(ids)
+    loader = DataLoader(ids=ids, verbose=False)
+    og = U.oracle_graph(ids, "test")
+    nodes = np.stack([np.arange(len(fx["subs"])), fx["subs"]], 1).astype(np.int64)
+    for i in range(int(fx["cfg"][0])):
+        t_nodes, t_edges, t_old = orc.get_neighbors(og, nodes)
+        g_nodes, g_edges, g_old = loader.get_neighbors(nodes, mode="test")
+        assert g_nodes.dtype == torch.int64 and g_nodes.is_cuda
+        assert np.array_equal(g_nodes.cpu().numpy(), t_nodes)
+        assert np.array_equal(g_nodes.cpu().numpy(), fx["L%d_nodes" % i])
+        assert np.array_equal(g_old.cpu().numpy(), t_old)
+        ge = g_edges.cpu().numpy()
+        assert ge.shape == t_edges.shape
+        assert np.array_equal(U.sorted_edges(ge), U.sorted_edges(t_edges))     # all six columns, as a multiset
+        assert U.edge_multiset_hash(ge) == str(fx["L%d_edge_hash" % i])
+        assert np.all(np.diff(ge[:, 5]) >= 0)                                   # destination-segmented
+        nodes = t_nodes
+
+
+@pytest.mark.parametrize("name,ids", [("tiny_fwd.npz", None), ("family_d48.npz", "family_ids.npz"),
+                                      ("family_d64.npz", "family_ids.npz"), ("umls_d48.npz", "umls_ids.npz")])
+def test_forward_matches_reference_fixture(name, ids):
+    fx = U.load(name)
+    ids = fx if ids is None else U.load(ids)
+    loader, model = make_model(fx, ids)
+    trace = []
+    with torch.no_grad():
+        scores = model(fx["subs"], fx["rels"], mode=str(fx["mode"]), trace=trace)
+    assert scores.is_cuda and scores.dtype == torch.float32 and tuple(scores.shape) == fx["scores"].shape
+    for i, t in enumerate(trace):
+        assert np.array_equal(t["nodes"].cpu().numpy(), fx["L%d_nodes" % i])
+        assert np.array_equal(t["old_nodes_new_idx"].cpu().numpy(), fx["L%d_old_nodes_new_idx" % i])
+        assert t["n_edges"] == int(fx["L%d_n_edges" % i])
+        if "L%d_hidden" % i in fx:
+            np.testing.assert_allclose(t["hidden"].cpu().numpy(), fx["L%d_hidden" % i], rtol=RTOL, atol=ATOL_H)
+    s = scores.cpu().numpy()
+    np.testing.assert_allclose(s, fx["scores"], rtol=RTOL, atol=ATOL)
+    assert np.array_equal(s == 0, fx["scores"] == 0)          # exact zeros at unvisited entities
+    # filtered ranks of this batch, on the device
+    from red_gnn_amd.utils import cal_ranks
+    n_ent = loader.n_ent
+    if "labels" in fx:
+        labels, filt = fx["labels"], fx["filters"]
+    else:
+        labels = np.zeros((len(fx["subs"]), n_ent)); labels[fx["labels_idx"][:, 0], fx["labels_idx"][:, 1]] = 1
+        filt = np.zeros((len(fx["subs"]), n_ent)); filt[fx["filters_idx"][:, 0], fx["filters_idx"][:, 1]] = 1
+    assert np.array_equal(np.array(cal_ranks(fx["scores"], labels, filt)), fx["ranks"])
+
+
+def test_forward_wn18rr_node_sets():
+    fx, ids = U.load("WN18RR_d48.npz"), U.load("WN18RR_ids.npz")
+    loader, model = make_model(fx, ids)
+    trace = []
+    with torch.no_grad():
+        scores = model(fx["subs"], fx["rels"], mode="test", trace=trace)
+    for i, t in enumerate(trace):
+        nodes = t["nodes"].cpu().numpy()
+        assert len(nodes) == int(fx["L%d_n_nodes" % i])
+        assert U.sha(nodes.astype(np.int64)) == str(fx["L%d_nodes_hash" % i])
+        assert t["n_edges"] == int(fx["L%d_n_edges" % i])
+    vis = trace[-1]["nodes"].cpu().numpy()
+    s = scores.cpu().numpy()
+    np.testing.assert_allclose(s[vis[:, 0], vis[:, 1]], fx["scores_visited"], rtol=RTOL, atol=ATOL)
+    assert np.count_nonzero(s) == int(fx["score_nnz"])
+
+
+def test_backward_matches_reference_fixture():
+    fx = U.load("tiny_bwd.npz")
+    loader, model = make_model(fx, fx, train=True)
+    scores = model(fx["subs"], fx["rels"], mode="train")
+    from red_gnn_amd.base_model import reference_loss
+    loss = reference_loss(scores, torch.as_tensor(fx["tails"], dtype=torch.long, device=scores.device))
+    assert abs(loss.item() - float(fx["loss"])) < 1e-4 * abs(float(fx["loss"]))
+    loss.backward()
+    grads = U.grads_of(fx)
+    for k, p in model.named_parameters():
+        np.testing.assert_allclose(p.grad.cpu().numpy(), grads[k], rtol=2e-3, atol=1e-5, err_msg=k)
+
+
+def test_rank_kernel_heavy_ties():
+    from red_gnn_amd.utils import cal_ranks, cal_performance
+    fx = U.load("ranks.npz")
+    ranks = cal_ranks(fx["scores"], fx["labels"], fx["filters"])
+    assert np.array_equal(np.array(ranks), fx["ranks"])
+    np.testing.assert_allclose(np.array(cal_performance(ranks)), fx["perf"], rtol=1e-12)
+
+
+def _random_model(loader, n_layer, d, a, act, seed=1234):
+    from red_gnn_amd.models import RED_GNN_trans
+    torch.manual_seed(seed)
+    model = RED_GNN_trans(P(n_layer, d, a, loader.n_rel, act), loader).cuda().eval()
+    return model
+
+
+@pytest.mark.parametrize("d,a,act,n_layer", [(16, 3, "idd", 2), (20, 5, "tanh", 3), (32, 5, "relu", 3), (48, 5, "relu", 3),
+                                            (64, 5, "relu", 3), (128, 10, "relu", 2), (30, 30, "tanh", 2)])
+def test_forward_vs_oracle_dims(d, a, act, n_layer):
+    """Every hidden/attention width the reference's presets use, incl. d % 4 != 0."""
+    from red_gnn_amd.load_data import DataLoader
+    from red_gnn_amd.synthetic import make_synthetic_kg
+    kg = make_synthetic_kg(300, 7, 3000, seed=3)
+    ids = dict(n_ent=kg.n_ent, n_rel=kg.n_rel, facts=kg.facts, train=kg.train, valid=kg.valid, test=kg.test)
+    loader = DataLoader(ids=ids, verbose=False)
+    model = _random_model(loader, n_layer, d, a, act)
+    rng = np.random.default_rng(0)
+    subs, rels = rng.integers(0, kg.n_ent, 9), rng.integers(0, 2 * kg.n_rel, 9)
+    with torch.no_grad():
+        s = model(subs, rels, mode="test").cpu().numpy()
+    p = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    ref = orc.forward(p, U.oracle_graph(ids, "test"), subs, rels, n_layer, act=act).numpy()
+    np.testing.assert_allclose(s, ref, rtol=RTOL, atol=ATOL)
+    assert np.array_equal(s == 0, ref == 0)
+
+
+def test_forward_vs_oracle_c2_shape_small_batch():
+    """BASELINE config 2 (10k entities / 50 relations / 200k triples, L=3, d=64) at a batch the oracle
+    finishes in seconds; hubs with in-degree in the thousands exercise the long-row path."""
+    from red_gnn_amd.load_data import DataLoader
+    from red_gnn_amd.synthetic import make_shape
+    kg = make_shape("C2")
+    ids = dict(n_ent=kg.n_ent, n_rel=kg.n_rel, facts=kg.facts, train=kg.train, valid=kg.valid, test=kg.test)
+    loader = DataLoader(ids=ids, verbose=False)
+    model = _random_model(loader, 3, 64, 5, "relu")
+    subs, rels = kg.test[:6, 0], kg.test[:6, 1]
+    trace = []
+    with torch.no_grad():
+        s = model(subs, rels, mode="test", trace=trace).cpu().numpy()
+    p = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    otrace = []
+    ref = orc.forward(p, U.oracle_graph(ids, "test"), subs, rels, 3, act="relu", trace=otrace).numpy()
+    for t, o in zip(trace, otrace):
+        assert np.array_equal(t["nodes"].cpu().numpy(), o["nodes"])
+        assert t["n_edges"] == len(o["edges"])
+    np.testing.assert_allclose(s, ref, rtol=RTOL, atol=2e-5)
+
+
+def test_backward_vs_oracle_autograd():
+    """Gradients of every parameter on a KG larger than the tiny fixture (LDS-privatised relation
+    gradients, multi-block flush), against torch autograd through the oracle."""
+    from red_gnn_amd.load_data import DataLoader
+    from red_gnn_amd.models import RED_GNN_trans
+    from red_gnn_amd.base_model import reference_loss
+    from red_gnn_amd.synthetic import make_synthetic_kg
+    kg = make_synthetic_kg(400, 6, 4000, seed=11)
+    ids = dict(n_ent=kg.n_ent, n_rel=kg.n_rel, facts=kg.facts, train=kg.train, valid=kg.valid, test=kg.test)
+    loader = DataLoader(ids=ids, verbose=False)
+    torch.manual_seed(5)
+    model = RED_GNN_trans(P(3, 32, 5, loader.n_rel, "tanh"), loader).cuda().train()
+    trip = loader.train_data[:12]
+    scores = model(trip[:, 0], trip[:, 1], mode="train")
+    loss = reference_loss(scores, torch.as_tensor(trip[:, 2], device=scores.device))
+    loss.backward()
+    p = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.named_parameters()}
+    os_ = orc.forward(p, U.oracle_graph(ids, "train"), trip[:, 0], trip[:, 1], 3, act="tanh")
+    ol = orc.loss_fn(os_, trip[:, 2])
+    ol.backward()
+    assert abs(loss.item() - ol.item()) < 1e-4 * abs(ol.item())
+    for k, v in model.named_parameters():
+        np.testing.assert_allclose(v.grad.cpu().numpy(), p[k].grad.numpy(), rtol=2e-3, atol=2e-5, err_msg=k)
+
+
+def test_full_size_properties_c2():
+    """BASELINE config 2 at bench batch size: properties that need no oracle run.
+    (1) per-query independence: a query's score row does not depend on its batch mates;
+    (2) determinism: two runs are bit-identical (destination-ordered sums, no float atomics);
+    (3) visited sets grow monotonically and edge counts equal sum of out-degrees of the frontier."""
+    from red_gnn_amd.load_data import DataLoader
+    from red_gnn_amd.synthetic import make_shape
+    kg = make_shape("C2")
+    ids = dict(n_ent=kg.n_ent, n_rel=kg.n_rel, facts=kg.facts, train=kg.train, valid=kg.valid, test=kg.test)
+    loader = DataLoader(ids=ids, verbose=False)
+    model = _random_model(loader, 3, 64, 5, "relu")
+    B = 256
+    subs, rels = kg.test[:B, 0], kg.test[:B, 1]
+    trace = []
+    with torch.no_grad():
+        s1 = model(subs, rels, mode="test", trace=trace)
+        s2 = model(subs, rels, mode="test")
+        s_sub = model(subs[100:108], rels[100:108], mode="test")
+    assert torch.equal(s1, s2)
+    # (the dense GEMMs are rocBLAS calls whose tiling depends on the row count, so not bitwise)
+    np.testing.assert_allclose(s_sub.cpu().numpy(), s1[100:108].cpu().numpy(), rtol=RTOL, atol=ATOL)
+    assert torch.equal(s_sub == 0, s1[100:108] == 0)
+    og = U.oracle_graph(ids, "test")
+    outdeg = np.diff(og.head_ptr)
+    prev = np.stack([np.arange(B), subs], 1)
+    for t in trace:
+        nodes = t["nodes"].cpu().numpy()
+        key = nodes[:, 0].astype(np.int64) * kg.n_ent + nodes[:, 1]
+        assert np.all(np.diff(key) > 0)                                  # sorted, unique
+        pkey = prev[:, 0].astype(np.int64) * kg.n_ent + prev[:, 1]
+        assert np.all(np.isin(pkey, key))                                # monotone frontier
+        assert t["n_edges"] == int(outdeg[prev[:, 1]].sum())             # E = sum of out-degrees
+        prev = nodes
