@@ -34,6 +34,9 @@ def lib():
         raise NativeError(
             "libredgnn.so is missing at %s: the HIP extension is not built. Run "
             "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). There is no CPU fallback." % LIB_PATH)
+    # torch bundles its own HIP runtime (libamdhip64.so.7); it must be loaded first so that this
+    # library binds to the SAME runtime (one device context, shared streams and allocations).
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t
     L.rg_last_error.restype = C.c_char_p

@@ -11,6 +11,10 @@ import torch
 from . import _lib
 
 
+# bench.py sets this to a list to collect (start_event, end_event, n_edges, n_new) per rg_layer_fwd launch
+KERNEL_EVENTS = None
+
+
 def _require_gpu(device):
     device = torch.device(device)
     if device.type != "cuda":
@@ -144,10 +148,17 @@ def layer_fwd(frontier, graph, level, nodes_new, hidden, rela, d, a_s, a_r, a_q,
     assert rela.shape[1] == ld and a_r.shape[1] == ap and a_q.shape[1] == ap
     n_new = nodes_new.shape[0]
     agg = torch.empty((n_new, ld), dtype=torch.float32, device=hidden.device)
+    ev = None
+    if KERNEL_EVENTS is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
     _lib.check(_lib.lib().rg_layer_fwd(frontier.handle, graph.handle, level, _lib.ptr(nodes_new), n_new,
                                        _lib.ptr(hidden), _lib.ptr(rela), d, ld, _lib.ptr(a_s), _lib.ptr(a_r),
                                        _lib.ptr(a_q), ap, _lib.ptr(w_alpha), _lib.ptr(b_alpha), attn_dim,
                                        _lib.ptr(agg), _lib.stream_ptr()))
+    if ev is not None:
+        ev[1].record()
+        KERNEL_EVENTS.append((ev[0], ev[1], frontier.n_edges, n_new))
     return agg
 
 

@@ -1,0 +1,65 @@
+"""Query sharding over GPUs (one process per GPU, torch.distributed; backend "nccl" is RCCL on ROCm).
+
+Every query builds its own subgraph (the batch index is carried through the whole path,
+Static/transductive/models.py:73, load_data.py:115-123), so the batch shards with no data-path
+collective: each rank holds a full replica of the KG and of the weights and runs the hot path on its
+slice of the queries.  The only exchanges are at the edges of the path: an all-gather of the score
+shards (evaluation, as BASELINE.json's north star specifies) or an all-reduce of four metric sums, and
+an all-reduce of the parameter gradients in training (the loss is a sum over queries, so gradients add).
+The functions take the process-group module as an argument so they run under gloo on CPU in tests.
+"""
+import torch
+
+
+def shard_slice(n, world, rank):
+    """Contiguous, balanced split of n items: the first n % world ranks get one extra."""
+    base, extra = divmod(n, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def shard_by_cost(costs, world):
+    """Greedy longest-processing-time split of queries by an estimated cost (e.g. out-degree of the
+    query subject: per-query subgraphs differ by >2x).  Returns a list of index lists."""
+    import numpy as np
+    order = np.argsort(-np.asarray(costs, dtype=np.float64), kind="stable")
+    loads = [0.0] * world
+    parts = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda k: (loads[k], k))
+        parts[r].append(int(i))
+        loads[r] += float(costs[i])
+    return [sorted(p) for p in parts]
+
+
+def gather_scores(local_scores, dist, sizes=None):
+    """All-gather of [b_r, n_ent] score shards into [sum b_r, n_ent] on every rank (rank order)."""
+    world = dist.get_world_size()
+    if sizes is None:
+        out = torch.empty((world * local_scores.shape[0], local_scores.shape[1]), dtype=local_scores.dtype, device=local_scores.device)
+        dist.all_gather_into_tensor(out, local_scores.contiguous())
+        return out
+    bufs = [torch.empty((s, local_scores.shape[1]), dtype=local_scores.dtype, device=local_scores.device) for s in sizes]
+    dist.all_gather(bufs, local_scores.contiguous())
+    return torch.cat(bufs, 0)
+
+
+def reduce_metrics(sums, dist):
+    """All-reduce of (sum 1/rank, #rank<=1, #rank<=10, count); MRR / H@k follow by division."""
+    sums = sums.clone()
+    dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+    return sums
+
+
+def allreduce_gradients(params, dist):
+    """One flat all-reduce (sum) of all parameter gradients (<= 0.7 MB for every preset)."""
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads:
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    off = 0
+    for g in grads:
+        n = g.numel()
+        g.copy_(flat[off:off + n].view_as(g))
+        off += n
