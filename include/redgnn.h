@@ -89,14 +89,16 @@ int rg_frontier_edges(const rg_frontier* f, const rg_graph* g, int32_t level,
  * projections a_s = hidden Ws^T [N_old,ap], a_r = rela Wr^T [2R+1,ap], a_q = rela[q_rel] Wqr^T + b [B,ap]
  * (ap = attention dim padded to a multiple of 4, pad columns zero).  Edges are enumerated
  * from the CSR-by-tail of `g` and the frontier bitmaps; no edge list is materialised.
- * nodes_new int32 [N_new,2]; hidden [N_old, ld], rela [2R+1, ld], agg_out [N_new, ld];
- * ld % 4 == 0, ld >= d, pad columns of hidden/rela must be zero. */
-int rg_layer_fwd(const rg_frontier* f, const rg_graph* g, int32_t level,
-                 const int32_t* nodes_new, int64_t n_new,
+ * hidden [N_old, ld], rela [2R+1, ld], agg_out [N_new, ld] (every row is written);
+ * ld % 4 == 0, ld >= d, pad columns of hidden/rela must be zero.  n_new is checked against the
+ * frontier.  scratch: device memory of rg_layer_fwd_scratch_bytes() bytes (partial sums of hub
+ * destinations that are cut into segments), 16-B aligned. */
+size_t rg_layer_fwd_scratch_bytes(const rg_frontier* f, const rg_graph* g, int32_t ld);
+int rg_layer_fwd(const rg_frontier* f, const rg_graph* g, int32_t level, int64_t n_new,
                  const float* hidden, const float* rela, int32_t d, int32_t ld,
                  const float* a_s, const float* a_r, const float* a_q, int32_t ap,
                  const float* w_alpha, const float* b_alpha, int32_t attn_dim,
-                 float* agg_out, void* stream);
+                 float* agg_out, void* scratch_dev, size_t scratch_bytes, void* stream);
 
 /* ---- layer backward: adjoint of rg_layer_fwd (autograd of models.py:29-39) --------------------
  * nodes_old int32 [N_old,2] (level-1).  grad_agg [N_new, ld].  grad_hidden [N_old, ld] and

@@ -44,6 +44,19 @@ int scan_exclusive(const uint32_t* in, int32_t* out, int64_t n, bool popc, int32
 }  // namespace rg
 
 // ---- handles ----------------------------------------------------------------------------------
+// Virtual rows: the CSR rows of one direction cut into segments of at most RG_VROW_MAX entries and
+// sorted by length (descending).  Neighbouring work items then have similar trip counts (no idle
+// lane groups next to a hub) and a hub of in-degree 17k becomes 133 independent items.
+// rows[i] = {entity, first entry, length, slot}: slot = -1 for an entity kept whole, else the index of
+// this segment's partial sum inside the query's `n_slots` partial rows.
+// split[i] = {entity, first slot, number of segments, 0}.
+constexpr int RG_VROW_MAX = 128;
+struct rg_vrows {
+  int32_t n = 0, n_split = 0, n_slots = 0;
+  int4* rows = nullptr;
+  int4* split = nullptr;
+};
+
 struct rg_graph {
   int32_t n_ent = 0, n_rel = 0;
   int64_t n_fact = 0;
@@ -54,6 +67,7 @@ struct rg_graph {
   // CSR by tail: in_ptr[n_ent+1], in_hr[n_fact] = {head, rel}
   int32_t* in_ptr = nullptr;
   int2* in_hr = nullptr;
+  rg_vrows in_vr, out_vr;
 };
 
 // Frontier state, all inside the caller's workspace.
@@ -69,7 +83,7 @@ struct rg_frontier {
   uint32_t* words_tmp = nullptr;     // [B][W] batch-major words before packing
   int32_t* prefix_tmp = nullptr;     // [B][W]
   int32_t* scan_scratch = nullptr;
-  int32_t* counters = nullptr;       // device: [0]=N (int32), [1]=error flag, [2..3]=E (uint64)
+  int32_t* counters = nullptr;       // device: [0]=N (int32), [1]=error flag, [2..3]=E (uint64), [4]=N of level 0, [16..23]=work queues
   int64_t* counts_pinned = nullptr;  // host pinned [4]
   int level = -1;                    // newest level (absolute, not modulo)
   int tcur = 0;                      // which bitsT holds the newest level

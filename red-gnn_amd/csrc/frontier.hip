@@ -181,7 +181,7 @@ size_t ws_layout(int32_t n_ent, int32_t B, int32_t n_levels, size_t* off /*[8]*/
   off[2] = take((size_t)B * W * 4);                          // words_tmp
   off[3] = take((size_t)B * W * 4);                          // prefix_tmp
   off[4] = take(rg::scan_scratch_elems((int64_t)B * W) * 4); // scan scratch
-  off[5] = take(64);                                         // counters
+  off[5] = take(256);                                        // counters + work queues
   off[6] = take((size_t)n_levels * B * W * 8);               // bm levels
   return o;
 }
@@ -253,7 +253,7 @@ int rg_frontier_reset(rg_frontier* f, const int32_t* q_sub, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   f->level = 0; f->tcur = 0; f->n_edges = 0;
   RG_HIP(hipMemsetAsync(f->bitsT[0], 0, (size_t)f->n_ent * f->BW * 4, s));
-  RG_HIP(hipMemsetAsync(f->counters, 0, 64, s));
+  RG_HIP(hipMemsetAsync(f->counters, 0, 256, s));
   hipLaunchKernelGGL(reset_kernel, dim3(rg::ceil_div(f->B, 256)), dim3(256), 0, s, q_sub, f->B, f->n_ent, f->BW,
                      f->bitsT[0], f->counters);
   RG_LAUNCH_CHECK();
@@ -268,7 +268,7 @@ int rg_frontier_reset_nodes(rg_frontier* f, const int32_t* nodes, int64_t n, voi
   hipStream_t s = (hipStream_t)stream;
   f->level = 0; f->tcur = 0; f->n_edges = 0;
   RG_HIP(hipMemsetAsync(f->bitsT[0], 0, (size_t)f->n_ent * f->BW * 4, s));
-  RG_HIP(hipMemsetAsync(f->counters, 0, 64, s));
+  RG_HIP(hipMemsetAsync(f->counters, 0, 256, s));
   if (n > 0) {
     hipLaunchKernelGGL(reset_nodes_kernel, dim3(rg::ceil_div(n, 256)), dim3(256), 0, s, nodes, n, f->B, f->n_ent, f->BW,
                        f->bitsT[0], f->counters);

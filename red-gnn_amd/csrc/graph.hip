@@ -4,6 +4,7 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "common.h"
@@ -141,6 +142,33 @@ int scan_exclusive(const uint32_t* in, int32_t* out, int64_t n, bool popc, int32
 
 }  // namespace rg
 
+// cut CSR rows into length-sorted virtual rows (see common.h) and upload them
+static int build_vrows(const std::vector<int32_t>& ptr, int32_t n_ent, rg_vrows* out) {
+  std::vector<int4> rows, split;
+  int32_t slots = 0;
+  for (int32_t e = 0; e < n_ent; ++e) {
+    const int32_t beg = ptr[e], len = ptr[e + 1] - ptr[e];
+    if (len <= RG_VROW_MAX) {
+      rows.push_back(make_int4(e, beg, len, -1));
+    } else {
+      const int32_t n_seg = (len + RG_VROW_MAX - 1) / RG_VROW_MAX;
+      split.push_back(make_int4(e, slots, n_seg, 0));
+      for (int32_t k = 0; k < n_seg; ++k) {
+        const int32_t b = beg + k * RG_VROW_MAX;
+        rows.push_back(make_int4(e, b, std::min(RG_VROW_MAX, beg + len - b), slots + k));
+      }
+      slots += n_seg;
+    }
+  }
+  std::stable_sort(rows.begin(), rows.end(), [](const int4& a, const int4& b) { return a.z > b.z; });
+  out->n = (int32_t)rows.size(); out->n_split = (int32_t)split.size(); out->n_slots = slots;
+  RG_HIP(hipMalloc(&out->rows, std::max<size_t>(rows.size(), 1) * sizeof(int4)));
+  RG_HIP(hipMalloc(&out->split, std::max<size_t>(split.size(), 1) * sizeof(int4)));
+  RG_HIP(hipMemcpy(out->rows, rows.data(), rows.size() * sizeof(int4), hipMemcpyHostToDevice));
+  if (!split.empty()) RG_HIP(hipMemcpy(out->split, split.data(), split.size() * sizeof(int4), hipMemcpyHostToDevice));
+  return 0;
+}
+
 extern "C" {
 
 const char* rg_last_error(void) { return rg::g_err.c_str(); }
@@ -197,6 +225,7 @@ int rg_graph_create(int32_t n_ent, int32_t n_rel, const int32_t* triples, int64_
   RG_HIP_G(hipMemcpy(g->out_rt, out_rt.data(), n_fact * sizeof(int2), hipMemcpyHostToDevice));
   RG_HIP_G(hipMemcpy(g->in_hr, in_hr.data(), n_fact * sizeof(int2), hipMemcpyHostToDevice));
 #undef RG_HIP_G
+  if (build_vrows(in_ptr, n_ent, &g->in_vr) || build_vrows(out_ptr, n_ent, &g->out_vr)) return fail();
   *out = g;
   return 0;
 }
@@ -207,6 +236,10 @@ int rg_graph_destroy(rg_graph* g) {
   if (g->in_ptr) (void)hipFree(g->in_ptr);
   if (g->out_rt) (void)hipFree(g->out_rt);
   if (g->in_hr) (void)hipFree(g->in_hr);
+  for (rg_vrows* v : {&g->in_vr, &g->out_vr}) {
+    if (v->rows) (void)hipFree(v->rows);
+    if (v->split) (void)hipFree(v->split);
+  }
   delete g;
   return 0;
 }

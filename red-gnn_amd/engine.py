@@ -128,6 +128,13 @@ class Frontier:
                                        _lib.ptr(row_ptr), _lib.ptr(scratch), _lib.stream_ptr()))
         return edges, row_ptr
 
+    def scratch(self, nbytes):
+        """A reusable device scratch buffer of at least nbytes (kernels' partial-sum space)."""
+        buf = getattr(self, "_scratch", None)
+        if buf is None or buf.numel() < nbytes:
+            buf = self._scratch = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
+        return buf
+
     def close(self):
         if getattr(self, "handle", None) is not None and _lib._lib is not None:
             _lib.lib().rg_frontier_destroy(self.handle)
@@ -148,14 +155,16 @@ def layer_fwd(frontier, graph, level, nodes_new, hidden, rela, d, a_s, a_r, a_q,
     assert rela.shape[1] == ld and a_r.shape[1] == ap and a_q.shape[1] == ap
     n_new = nodes_new.shape[0]
     agg = torch.empty((n_new, ld), dtype=torch.float32, device=hidden.device)
+    nbytes = _lib.lib().rg_layer_fwd_scratch_bytes(frontier.handle, graph.handle, ld)
+    scratch = frontier.scratch(nbytes)
     ev = None
     if KERNEL_EVENTS is not None:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
-    _lib.check(_lib.lib().rg_layer_fwd(frontier.handle, graph.handle, level, _lib.ptr(nodes_new), n_new,
+    _lib.check(_lib.lib().rg_layer_fwd(frontier.handle, graph.handle, level, n_new,
                                        _lib.ptr(hidden), _lib.ptr(rela), d, ld, _lib.ptr(a_s), _lib.ptr(a_r),
                                        _lib.ptr(a_q), ap, _lib.ptr(w_alpha), _lib.ptr(b_alpha), attn_dim,
-                                       _lib.ptr(agg), _lib.stream_ptr()))
+                                       _lib.ptr(agg), _lib.ptr(scratch), nbytes, _lib.stream_ptr()))
     if ev is not None:
         ev[1].record()
         KERNEL_EVENTS.append((ev[0], ev[1], frontier.n_edges, n_new))
