@@ -113,6 +113,23 @@ int rg_layer_bwd(const rg_frontier* f, const rg_graph* g, int32_t level,
                  float* grad_hidden, float* grad_rela, float* grad_a_s, float* grad_a_r,
                  float* grad_a_q, float* grad_w_alpha, float* grad_b_alpha, void* stream);
 
+/* ---- dense epilogue of a layer (inference): replaces models.py:41 (W_h + act), :81 (h0 index_copy_, as a
+ * gather by prev_idx), :82-84 (single-step nn.GRU; dropout = identity in eval), the next layer's
+ * Ws_attn projection (:36, hoisted per node) and, on the last layer, :86-88 (W_final + scatter into
+ * scores_all).  One f32-MFMA kernel; weights in the layouts of the reference's state dict:
+ * W_h [d,d], weight_ih_l0 / weight_hh_l0 [3d,d] (gate rows r,z,n), bias_* [3d], Ws_next [attn,d] or NULL,
+ * W_final [d] or NULL.  agg [n,ld], hidden_prev [n_old,ld], prev_idx int32 [n] (-1 = new node; NULL = all
+ * new), a_s_out [n,ap], nodes int32 [n,2], scores_all [B*n_ent] (pre-zeroed; only visited entries are
+ * written), hidden_out [n,ld].  act: 0 identity, 1 relu, 2 tanh.  Supported: d <= 64, attn_dim <= 16
+ * (rg_dense_fwd_supported); other shapes return an error and the caller keeps its own dense path. */
+int rg_dense_fwd_supported(int32_t d, int32_t attn_dim);
+int rg_dense_fwd(int64_t n, int32_t d, int32_t ld, const float* agg, const float* hidden_prev,
+                 const int32_t* prev_idx, const float* W_h, int32_t act,
+                 const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                 const float* Ws_next, int32_t attn_dim, int32_t ap, float* a_s_out,
+                 const float* W_final, const int32_t* nodes, int32_t n_ent, float* scores_all,
+                 float* hidden_out, void* stream);
+
 /* ---- filtered ranking: replaces utils.py:7-14 cal_ranks (+ the filter loop base_model.py:107-115)
  * scores device fp32 [B, n_ent]; answers / filters as CSR over queries (device int32):
  * ans_ptr [B+1], ans_idx [ans_ptr[B]], filt_ptr [B+1], filt_idx [..].  ranks_out device fp32

@@ -1,0 +1,287 @@
+// Fused dense epilogue of one layer on f32 MFMA (inference path).
+// Replaces, per layer of RED_GNN_trans.forward (Static/transductive/models.py):
+//   :41     hidden_new = act(W_h(message_agg))
+//   :81     h0 = zeros(...).index_copy_(1, old_nodes_new_idx, h0)         (as a gather by prev_idx)
+//   :82-84  single-step nn.GRU  (dropout is the identity in eval mode)
+//   next layer's :36 Ws_attn(hs), hoisted to per-node  a_s = hidden Ws^T
+//   :86-88  W_final(hidden) scattered into scores_all                    (last layer)
+// i.e. three rocBLAS GEMMs + gru_cell + index_copy + fills + two N x 3d temporaries become one kernel
+// that reads agg and the gathered old state once and writes hidden, a_s (and scores) once.
+//
+// Every product is computed TRANSPOSED with v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains):
+//   out^T[w_row][node] = sum_k W[w_row][k] * X[node][k]      A = W (LDS),  B = X rows (one node per lane)
+// so the 32 nodes of a wave's tile sit on the lanes (node = lane & 31) for inputs AND outputs, the
+// output's w_row index lives in the 16 accumulator registers, and an accumulator tile is directly the B
+// operand of the next product (no LDS round trip between W_h, the GRU gates and the projections):
+// lane half h = lane >> 5 owns the k-subset  k(h, m) = 32*(m/16) + 8*((m%16)/4) + 4*h + (m%4),
+// which is exactly the set of accumulator rows the lane holds.  Weights stay in LDS for the whole
+// kernel (XOR-swizzled 16-B slots, conflict-free ds_read_b128), one persistent workgroup per CU.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct DenseArgs {
+  int64_t n;
+  int d, ld4;              // true width, row stride in float4
+  const float4* agg;
+  const float4* hprev;     // [n_old][ld4]
+  const int32_t* prev_idx; // [n] or null (all new)
+  const float* W_h;        // [d][d]
+  const float* w_ih;       // [3d][d]
+  const float* w_hh;
+  const float* b_ih;       // [3d]
+  const float* b_hh;
+  const float* Ws;         // [attn][d] or null
+  int attn, ap;
+  float* a_s_out;          // [n][ap]
+  const float* W_final;    // [d] or null
+  const int32_t* nodes;    // [n][2]
+  int n_ent;
+  float* scores;           // [B*n_ent]
+  float4* hidden_out;      // [n][ld4]
+  int act;                 // 0 idd, 1 relu, 2 tanh
+  int n_tiles;
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// LDS images: rows of DP floats, 16-B slot index XOR-swizzled with the row so that 16 lanes reading the same
+// logical slot of 16 different rows hit 16 different bank groups.
+template <int DP>
+__device__ __forceinline__ int sw(int row, int slot) { return row * (DP / 4) + (slot ^ (row & (DP / 4 - 1))); }
+
+template <int NB>
+__global__ __launch_bounds__(256, 1) void dense_kernel(DenseArgs A) {
+  constexpr int DP = 32 * NB;      // padded width
+  constexpr int S = DP / 4;        // 16-B slots per row
+  constexpr int KS = 16 * NB;      // MFMA k-steps per product = B-fragment registers
+  extern __shared__ float4 lds[];
+  float4* Wh_l = lds;                         // [DP rows][S]
+  float4* Wih_l = Wh_l + DP * S;              // [3*DP][S]   gate g rows at g*DP
+  float4* Whh_l = Wih_l + 3 * DP * S;         // [3*DP][S]
+  float4* E_l = Whh_l + 3 * DP * S;           // [32][S]     rows 0..ap-1 = Ws, row 16 = W_final
+  float* bias_l = reinterpret_cast<float*>(E_l + 32 * S);   // [4][DP]: b_ir+b_hr, b_iz+b_hz, b_in, b_hn
+  float4* tiles = reinterpret_cast<float4*>(bias_l + 4 * DP);   // [4 waves][32 rows][S]
+
+  const int d = A.d;
+  // ---- weights -> LDS (zero padded, swizzled) ----------------------------------------------------------
+  auto load_w = [&](float4* dst, const float* src, int rows_src, int row0_dst, int rows_dst) {
+    for (int i = threadIdx.x; i < rows_dst * S; i += 256) {
+      const int r = i / S, sl = i - r * S;
+      float v[4];
+      for (int k = 0; k < 4; ++k) {
+        const int c = sl * 4 + k;
+        v[k] = (src && r < rows_src && c < d) ? src[(int64_t)r * d + c] : 0.f;
+      }
+      dst[sw<DP>(row0_dst + r, sl)] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  };
+  load_w(Wh_l, A.W_h, d, 0, DP);
+  for (int g = 0; g < 3; ++g) {
+    load_w(Wih_l, A.w_ih + (int64_t)g * d * d, d, g * DP, DP);
+    load_w(Whh_l, A.w_hh + (int64_t)g * d * d, d, g * DP, DP);
+  }
+  load_w(E_l, A.Ws, A.Ws ? A.attn : 0, 0, 16);
+  load_w(E_l, A.W_final, A.W_final ? 1 : 0, 16, 16);
+  for (int i = threadIdx.x; i < 4 * DP; i += 256) {
+    const int g = i / DP, c = i - g * DP;
+    float v = 0.f;
+    if (c < d) {
+      if (g == 0) v = A.b_ih[c] + A.b_hh[c];
+      else if (g == 1) v = A.b_ih[d + c] + A.b_hh[d + c];
+      else if (g == 2) v = A.b_ih[2 * d + c];
+      else v = A.b_hh[2 * d + c];
+    }
+    bias_l[i] = v;
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int li = lane & 31, h = lane >> 5;
+  float4* tile = tiles + wv * 32 * S;
+
+  // B fragment of the wave's staged tile: register m <- X[node li][k(h, m)]
+  auto read_frag = [&](float (&f)[KS]) {
+#pragma unroll
+    for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = tile[sw<DP>(li, 8 * jb + 2 * q + h)];
+        f[16 * jb + 4 * q + 0] = v.x; f[16 * jb + 4 * q + 1] = v.y; f[16 * jb + 4 * q + 2] = v.z; f[16 * jb + 4 * q + 3] = v.w;
+      }
+  };
+  // acc += W[row0 + (0..31)][:] . frag     (one 32-row block of a weight image)
+  auto mma = [&](const float4* W_l, int row0, const float (&f)[KS], f32x16 acc) -> f32x16 {
+#pragma unroll
+    for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 a = W_l[sw<DP>(row0 + li, 8 * jb + 2 * q + h)];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, f[16 * jb + 4 * q + 0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, f[16 * jb + 4 * q + 1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, f[16 * jb + 4 * q + 2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, f[16 * jb + 4 * q + 3], acc, 0, 0, 0);
+      }
+    return acc;
+  };
+  // accumulator row index of register r in this lane: (r&3) + 8*(r>>2) + 4*h
+  auto bias_acc = [&](int g, int ob) -> f32x16 {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = bias_l[g * DP + 32 * ob + (r & 3) + 8 * (r >> 2) + 4 * h];
+    return acc;
+  };
+
+  for (int t = blockIdx.x * 4 + wv; t < A.n_tiles; t += gridDim.x * 4) {
+    const int64_t row0 = (int64_t)t * 32;
+    // ---- stage agg tile (coalesced float4 rows) -----------------------------------------------------------
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 32 * S / 64; ++it) {
+      const int e = it * 64 + lane, r = e / S, sl = e - r * S;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row0 + r < A.n && sl < A.ld4) v = A.agg[(row0 + r) * A.ld4 + sl];
+      tile[sw<DP>(r, sl)] = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    float fx[KS];
+    read_frag(fx);
+
+    // ---- stage gathered old state (issue early; consumed after stage 1) -------------------------------------
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 32 * S / 64; ++it) {
+      const int e = it * 64 + lane, r = e / S, sl = e - r * S;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row0 + r < A.n && sl < A.ld4 && A.prev_idx) {
+        const int p = A.prev_idx[row0 + r];
+        if (p >= 0) v = A.hprev[(int64_t)p * A.ld4 + sl];
+      }
+      tile[sw<DP>(r, sl)] = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- stage 1: x = act(W_h agg)   (accumulators become the next B fragment) ---------------------------
+    float xf[KS];
+#pragma unroll
+    for (int ob = 0; ob < NB; ++ob) {
+      f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      acc = mma(Wh_l, 32 * ob, fx, acc);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = acc[r];
+        if (A.act == 1) v = fmaxf(v, 0.f);
+        else if (A.act == 2) v = tanhf(v);
+        xf[16 * ob + r] = v;
+      }
+    }
+    float hf[KS];
+    read_frag(hf);
+
+    // ---- GRU gates ([r; z; n] row blocks of weight_ih / weight_hh) -----------------------------------------
+    float hn[KS];
+#pragma unroll
+    for (int ob = 0; ob < NB; ++ob) {
+      f32x16 ar = bias_acc(0, ob);
+      ar = mma(Wih_l, 0 * DP + 32 * ob, xf, ar);
+      ar = mma(Whh_l, 0 * DP + 32 * ob, hf, ar);
+      f32x16 az = bias_acc(1, ob);
+      az = mma(Wih_l, 1 * DP + 32 * ob, xf, az);
+      az = mma(Whh_l, 1 * DP + 32 * ob, hf, az);
+      f32x16 ai = bias_acc(2, ob);
+      ai = mma(Wih_l, 2 * DP + 32 * ob, xf, ai);
+      f32x16 ah = bias_acc(3, ob);
+      ah = mma(Whh_l, 2 * DP + 32 * ob, hf, ah);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float rg = sigmoidf_(ar[r]), zg = sigmoidf_(az[r]);
+        const float ng = tanhf(ai[r] + rg * ah[r]);
+        hn[16 * ob + r] = (1.0f - zg) * ng + zg * hf[16 * ob + r];
+      }
+    }
+
+    // ---- projections of the new state: a_s (next layer) and score (last layer) ----------------------------------
+    if (A.Ws || A.W_final) {
+      f32x16 ae = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      ae = mma(E_l, 0, hn, ae);
+      const int64_t node = row0 + li;
+      if (node < A.n) {
+        if (A.Ws) {   // rows e = (r&3) + 8*(r>>2) + 4h: e in [4h, 4h+4) are regs 0..3, [8+4h, 8+4h+4) regs 4..7
+          float4* out = reinterpret_cast<float4*>(A.a_s_out + node * A.ap);
+          if (4 * h < A.ap) out[h] = make_float4(ae[0], ae[1], ae[2], ae[3]);
+          if (8 + 4 * h < A.ap) out[2 + h] = make_float4(ae[4], ae[5], ae[6], ae[7]);
+        }
+        if (A.W_final && h == 0) {   // row 16 = reg 8 of half 0
+          const int b = A.nodes[2 * node], e = A.nodes[2 * node + 1];
+          A.scores[(int64_t)b * A.n_ent + e] = ae[8];
+        }
+      }
+    }
+
+    // ---- new state: transpose through the tile, store coalesced rows ----------------------------------------------
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int jb = 0; jb < NB; ++jb)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        tile[sw<DP>(li, 8 * jb + 2 * q + h)] =
+            make_float4(hn[16 * jb + 4 * q + 0], hn[16 * jb + 4 * q + 1], hn[16 * jb + 4 * q + 2], hn[16 * jb + 4 * q + 3]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 32 * S / 64; ++it) {
+      const int e = it * 64 + lane, r = e / S, sl = e - r * S;
+      if (row0 + r < A.n && sl < A.ld4) A.hidden_out[(row0 + r) * A.ld4 + sl] = tile[sw<DP>(r, sl)];
+    }
+  }
+}
+
+template <int NB>
+int launch(const DenseArgs& A, hipStream_t s) {
+  constexpr int DP = 32 * NB, S = DP / 4;
+  const size_t lds = (size_t)(DP * S + 6 * DP * S + 32 * S) * sizeof(float4) + 4 * DP * sizeof(float) + (size_t)4 * 32 * S * sizeof(float4);
+  RG_HIP(hipFuncSetAttribute((const void*)dense_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int grid = (int)std::min<int64_t>(rg::ceil_div(A.n_tiles, 4), 256);
+  hipLaunchKernelGGL(dense_kernel<NB>, dim3(grid), dim3(256), lds, s, A);
+  RG_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int rg_dense_fwd_supported(int32_t d, int32_t attn_dim) { return d >= 1 && d <= 64 && attn_dim <= 16; }
+
+extern "C" int rg_dense_fwd(int64_t n, int32_t d, int32_t ld, const float* agg, const float* hidden_prev,
+                            const int32_t* prev_idx, const float* W_h, int32_t act, const float* w_ih, const float* w_hh,
+                            const float* b_ih, const float* b_hh, const float* Ws_next, int32_t attn_dim, int32_t ap,
+                            float* a_s_out, const float* W_final, const int32_t* nodes, int32_t n_ent, float* scores_all,
+                            float* hidden_out, void* stream) {
+  RG_CHECK(agg && W_h && w_ih && w_hh && b_ih && b_hh && hidden_out, "rg_dense_fwd: NULL argument");
+  RG_CHECK(!prev_idx || hidden_prev, "rg_dense_fwd: prev_idx given without hidden_prev");
+  RG_CHECK(d >= 1 && d <= 64, "rg_dense_fwd: hidden_dim %d not supported by the fused kernel (<= 64)", d);
+  RG_CHECK(ld >= d && ld % 4 == 0 && ld <= 64, "rg_dense_fwd: ld=%d", ld);
+  RG_CHECK(act >= 0 && act <= 2, "rg_dense_fwd: act=%d", act);
+  RG_CHECK(!Ws_next || (a_s_out && attn_dim >= 1 && attn_dim <= 16 && ap >= attn_dim && ap % 4 == 0 && ap <= 16),
+           "rg_dense_fwd: attn_dim=%d ap=%d not supported (<= 16)", attn_dim, ap);
+  RG_CHECK(!W_final || (nodes && scores_all && n_ent > 0), "rg_dense_fwd: readout needs nodes and scores_all");
+  RG_CHECK((((uintptr_t)agg | (uintptr_t)hidden_prev | (uintptr_t)hidden_out | (uintptr_t)a_s_out) & 15) == 0,
+           "rg_dense_fwd: float buffers must be 16-B aligned");
+  if (n == 0) return 0;
+  DenseArgs A;
+  A.n = n; A.d = d; A.ld4 = ld / 4;
+  A.agg = (const float4*)agg; A.hprev = (const float4*)hidden_prev; A.prev_idx = prev_idx;
+  A.W_h = W_h; A.w_ih = w_ih; A.w_hh = w_hh; A.b_ih = b_ih; A.b_hh = b_hh;
+  A.Ws = Ws_next; A.attn = attn_dim; A.ap = ap; A.a_s_out = a_s_out;
+  A.W_final = W_final; A.nodes = nodes; A.n_ent = n_ent; A.scores = scores_all;
+  A.hidden_out = (float4*)hidden_out; A.act = act;
+  A.n_tiles = (int)rg::ceil_div(n, 32);
+  hipStream_t s = (hipStream_t)stream;
+  return d <= 32 ? launch<1>(A, s) : launch<2>(A, s);
+}

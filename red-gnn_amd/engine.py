@@ -192,6 +192,27 @@ def layer_bwd(frontier, graph, level, nodes_old, hidden, rela, d, a_s, a_r, a_q,
     return g_h, g_rela, g_as, g_ar, g_aq, g_w, g_b
 
 
+def dense_supported(d, attn_dim):
+    return bool(_lib.lib().rg_dense_fwd_supported(d, attn_dim))
+
+
+def dense_fwd(agg, hidden_prev, prev_idx, d, W_h, act, gate, Ws_next=None, attn_dim=0, ap=0, W_final=None, nodes=None,
+              n_ent=0, scores_all=None):
+    """Fused W_h + act + GRU step (+ next layer's a_s, + readout) on f32 MFMA (rg_dense_fwd).
+    Returns (hidden_new [n, ld], a_s_next [n, ap] or None)."""
+    n, ld = agg.shape
+    hidden = torch.empty_like(agg)
+    a_s = torch.empty((n, ap), dtype=torch.float32, device=agg.device) if Ws_next is not None else None
+    c = lambda t: None if t is None else t.detach().contiguous()
+    W_h, w_ih, w_hh, b_ih, b_hh = c(W_h), c(gate.weight_ih_l0), c(gate.weight_hh_l0), c(gate.bias_ih_l0), c(gate.bias_hh_l0)
+    Ws_next, W_final = c(Ws_next), c(W_final)
+    _lib.check(_lib.lib().rg_dense_fwd(n, d, ld, _lib.ptr(agg), _lib.ptr(hidden_prev), _lib.ptr(prev_idx), _lib.ptr(W_h),
+                                       {"idd": 0, "relu": 1, "tanh": 2}[act], _lib.ptr(w_ih), _lib.ptr(w_hh), _lib.ptr(b_ih),
+                                       _lib.ptr(b_hh), _lib.ptr(Ws_next), attn_dim, ap, _lib.ptr(a_s), _lib.ptr(W_final),
+                                       _lib.ptr(nodes), n_ent, _lib.ptr(scores_all), _lib.ptr(hidden), _lib.stream_ptr()))
+    return hidden, a_s
+
+
 def rank(scores, ans_ptr, ans_idx, filt_ptr, filt_idx):
     """Filtered ranks (rg_rank) of every answer, fp32 [len(ans_idx)] in (query, answer) order."""
     assert scores.is_cuda and scores.dtype == torch.float32 and scores.is_contiguous()

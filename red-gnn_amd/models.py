@@ -61,6 +61,20 @@ class GNNLayer(nn.Module):
         self.w_alpha = nn.Linear(attn_dim, 1)
         self.W_h = nn.Linear(in_dim, out_dim, bias=False)
 
+    def aggregate_nograd(self, q_rel, hidden_p, a_s, frontier, graph, level, nodes_new):
+        """Inference form of ``aggregate``: hidden_p [n_old, ld] already padded, a_s [n_old, ap] given
+        (produced by the previous layer's fused dense kernel).  Returns agg [n_new, ld]."""
+        d, a = self.in_dim, self.attn_dim
+        ld, ap = hidden_p.shape[1], a_s.shape[1]
+        rela = self.rela_embed.weight
+        pad_rows = lambda w: F.pad(w, (0, 0, 0, ap - a)) if ap != a else w
+        a_r = F.linear(rela, pad_rows(self.Wr_attn.weight))
+        a_q = F.linear(rela[q_rel], pad_rows(self.Wqr_attn.weight), F.pad(self.Wqr_attn.bias, (0, ap - a)))
+        if ld != d:
+            rela = F.pad(rela, (0, ld - d))
+        return engine.layer_fwd(frontier, graph, level, nodes_new, hidden_p, rela.contiguous(), d, a_s, a_r.contiguous(),
+                                a_q.contiguous(), self.w_alpha.weight.reshape(-1).contiguous(), self.w_alpha.bias, a)
+
     def aggregate(self, q_rel, hidden, frontier, graph, level, nodes_new, nodes_old):
         """models.py:29-39 on the device; returns message_agg [n_new, in_dim]."""
         d, a = self.in_dim, self.attn_dim
@@ -87,6 +101,7 @@ class RED_GNN_trans(nn.Module):
         self.loader = loader
         acts = {"relu": nn.ReLU(), "tanh": torch.tanh, "idd": lambda x: x}
         act = acts[params.act]
+        self.act_name = params.act
         self.gnn_layers = nn.ModuleList(
             [GNNLayer(self.hidden_dim, self.hidden_dim, self.attn_dim, self.n_rel, act=act) for _ in range(self.n_layer)])
         self.dropout = nn.Dropout(params.dropout)
@@ -94,6 +109,7 @@ class RED_GNN_trans(nn.Module):
         self.gate = nn.GRU(self.hidden_dim, self.hidden_dim)     # parameters only; the single step runs as gru_cell
         self._frontiers = {}
         self.last_stats = None
+        self.fused_dense = True      # inference: W_h + GRU + projections + readout in one MFMA kernel (rg_dense_fwd)
 
     def _frontier(self, batch, n_levels, device):
         key = (batch, n_levels, str(device))
@@ -114,6 +130,8 @@ class RED_GNN_trans(nn.Module):
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         fr = self._frontier(n, self.n_layer + 1 if need_grad else 2, device)
         fr.reset(q_sub)
+        if not need_grad and self.fused_dense and engine.dense_supported(self.hidden_dim, self.attn_dim):
+            return self._forward_inference(fr, graph, q_sub, q_rel, n, device, trace)
 
         d = self.hidden_dim
         h0 = torch.zeros((n, d), device=device)                                  # models.py:72
@@ -138,3 +156,30 @@ class RED_GNN_trans(nn.Module):
         scores_all = torch.zeros(n * self.loader.n_ent, device=device).index_copy(0, key, scores)    # models.py:87-88
         self.last_stats = dict(n_edges=n_edges, n_nodes=int(nodes_old.shape[0]))
         return scores_all.view(n, self.loader.n_ent)
+
+    def _forward_inference(self, fr, graph, q_sub, q_rel, n, device, trace):
+        """The same forward with no autograd graph: per layer one expansion, one fused message-passing
+        kernel and one fused dense kernel; hidden / a_s never leave their padded device layout."""
+        d, a = self.hidden_dim, self.attn_dim
+        ld, ap = max(16, _pad4(d)), _pad4(a)
+        n_ent = self.loader.n_ent
+        hidden = torch.zeros((n, ld), device=device)
+        a_s = torch.zeros((n, ap), device=device)                     # hidden == 0 at layer 0 (models.py:74)
+        scores_all = torch.zeros(n * n_ent, device=device)           # models.py:87
+        n_edges = []
+        nodes = None
+        for i in range(self.n_layer):
+            n_new, n_e, _ = fr.expand(graph)
+            nodes, prev_idx, old_new = fr.nodes(want_prev=True, want_old_new=trace is not None)
+            n_edges.append(n_e)
+            layer = self.gnn_layers[i]
+            agg = layer.aggregate_nograd(q_rel, hidden, a_s, fr, graph, fr.level, nodes)
+            last = i + 1 == self.n_layer
+            hidden, a_s = engine.dense_fwd(
+                agg, hidden, prev_idx, d, layer.W_h.weight, self.act_name, self.gate,
+                Ws_next=None if last else self.gnn_layers[i + 1].Ws_attn.weight, attn_dim=a, ap=ap,
+                W_final=self.W_final.weight if last else None, nodes=nodes, n_ent=n_ent, scores_all=scores_all)
+            if trace is not None:
+                trace.append(dict(nodes=nodes, old_nodes_new_idx=old_new, n_edges=n_e, hidden=hidden[:, :d]))
+        self.last_stats = dict(n_edges=n_edges, n_nodes=int(nodes.shape[0]))
+        return scores_all.view(n, n_ent)

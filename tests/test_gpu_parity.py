@@ -254,3 +254,28 @@ def test_full_size_properties_c2():
         assert np.all(np.isin(pkey, key))                                # monotone frontier
         assert t["n_edges"] == int(outdeg[prev[:, 1]].sum())             # E = sum of out-degrees
         prev = nodes
+
+
+@pytest.mark.parametrize("d,a,act", [(64, 5, "relu"), (48, 5, "tanh"), (32, 3, "idd"), (20, 10, "relu"), (30, 16, "tanh")])
+def test_fused_dense_kernel_matches_torch_dense_path(d, a, act):
+    """rg_dense_fwd (f32 MFMA: W_h + act + GRU + next a_s + readout) against the same model with the
+    dense part in torch ops (rocBLAS + gru_cell): same nodes, hidden and scores."""
+    from red_gnn_amd.load_data import DataLoader
+    from red_gnn_amd.synthetic import make_synthetic_kg
+    kg = make_synthetic_kg(700, 9, 9000, seed=21)
+    ids = dict(n_ent=kg.n_ent, n_rel=kg.n_rel, facts=kg.facts, train=kg.train, valid=kg.valid, test=kg.test)
+    loader = DataLoader(ids=ids, verbose=False)
+    model = _random_model(loader, 3, d, a, act, seed=7)
+    rng = np.random.default_rng(1)
+    subs, rels = rng.integers(0, kg.n_ent, 37), rng.integers(0, 2 * kg.n_rel, 37)
+    t1, t2 = [], []
+    with torch.no_grad():
+        model.fused_dense = True
+        s1 = model(subs, rels, mode="test", trace=t1)
+        model.fused_dense = False
+        s2 = model(subs, rels, mode="test", trace=t2)
+    for x, y in zip(t1, t2):
+        assert torch.equal(x["nodes"], y["nodes"])
+        np.testing.assert_allclose(x["hidden"].cpu().numpy(), y["hidden"].cpu().numpy(), rtol=RTOL, atol=ATOL_H)
+    np.testing.assert_allclose(s1.cpu().numpy(), s2.cpu().numpy(), rtol=RTOL, atol=ATOL_H)
+    assert torch.equal(s1 == 0, s2 == 0)
