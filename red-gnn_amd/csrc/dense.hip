@@ -8,19 +8,20 @@
 // i.e. three rocBLAS GEMMs + gru_cell + index_copy + fills + two N x 3d temporaries become one kernel
 // that reads agg and the gathered old state once and writes hidden, a_s (and scores) once.
 //
-// Every product is computed TRANSPOSED with v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains):
+// Every product is computed TRANSPOSED with v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains):
 //   out^T[w_row][node] = sum_k W[w_row][k] * X[node][k]      A = W (LDS),  B = X rows (one node per lane)
-// so the 32 nodes of a wave's tile sit on the lanes (node = lane & 31) for inputs AND outputs, the
-// output's w_row index lives in the 16 accumulator registers, and an accumulator tile is directly the B
-// operand of the next product (no LDS round trip between W_h, the GRU gates and the projections):
-// lane half h = lane >> 5 owns the k-subset  k(h, m) = 32*(m/16) + 8*((m%16)/4) + 4*h + (m%4),
+// so the 16 nodes of a wave's tile sit on the lanes (node = lane & 15) for inputs AND outputs, the
+// output's w_row index lives in the 4 accumulator registers of a 16-row block, and an accumulator tile is
+// directly the B operand of the next product (no LDS round trip between W_h, the GRU gates and the
+// projections): lane quarter hq = lane >> 4 owns the k-subset  k(hq, m) = 16*(m/4) + 4*hq + (m%4),
 // which is exactly the set of accumulator rows the lane holds.  Weights stay in LDS for the whole
-// kernel (XOR-swizzled 16-B slots, conflict-free ds_read_b128), one persistent workgroup per CU.
+// kernel (XOR-swizzled 16-B slots, conflict-free ds_read_b128); one persistent 8-wave workgroup per CU
+// (2 waves per SIMD: one wave's loads and transcendentals hide under the other's MFMAs).
 #include "common.h"
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct DenseArgs {
   int64_t n;
@@ -45,30 +46,38 @@ struct DenseArgs {
   int n_tiles;
 };
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// v_exp_f32 / v_rcp_f32 forms (1 ulp each): far inside the 1e-4 relative tolerance of the path
+__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) {
+  const float e = __expf(-2.0f * fabsf(x));            // in (0, 1]: no overflow
+  return copysignf((1.0f - e) * __frcp_rn(1.0f + e), x);
+}
 
 // LDS images: rows of DP floats, 16-B slot index XOR-swizzled with the row so that 16 lanes reading the same
 // logical slot of 16 different rows hit 16 different bank groups.
 template <int DP>
 __device__ __forceinline__ int sw(int row, int slot) { return row * (DP / 4) + (slot ^ (row & (DP / 4 - 1))); }
 
-template <int NB>
-__global__ __launch_bounds__(256, 1) void dense_kernel(DenseArgs A) {
-  constexpr int DP = 32 * NB;      // padded width
+constexpr int DENSE_T = 512;   // 8 waves
+
+template <int NB>   // DP = 16 * NB, NB in {2, 4}
+__global__ __launch_bounds__(DENSE_T, 2) void dense_kernel(DenseArgs A) {
+  constexpr int DP = 16 * NB;      // padded width
   constexpr int S = DP / 4;        // 16-B slots per row
-  constexpr int KS = 16 * NB;      // MFMA k-steps per product = B-fragment registers
+  constexpr int KS = DP / 4;       // MFMA k-steps per product = B-fragment registers
+  constexpr int NW = DENSE_T / 64;
   extern __shared__ float4 lds[];
   float4* Wh_l = lds;                         // [DP rows][S]
   float4* Wih_l = Wh_l + DP * S;              // [3*DP][S]   gate g rows at g*DP
   float4* Whh_l = Wih_l + 3 * DP * S;         // [3*DP][S]
   float4* E_l = Whh_l + 3 * DP * S;           // [32][S]     rows 0..ap-1 = Ws, row 16 = W_final
   float* bias_l = reinterpret_cast<float*>(E_l + 32 * S);   // [4][DP]: b_ir+b_hr, b_iz+b_hz, b_in, b_hn
-  float4* tiles = reinterpret_cast<float4*>(bias_l + 4 * DP);   // [4 waves][32 rows][S]
+  float4* tiles = reinterpret_cast<float4*>(bias_l + 4 * DP);   // [NW waves][16 rows][S]
 
   const int d = A.d;
   // ---- weights -> LDS (zero padded, swizzled) ----------------------------------------------------------
   auto load_w = [&](float4* dst, const float* src, int rows_src, int row0_dst, int rows_dst) {
-    for (int i = threadIdx.x; i < rows_dst * S; i += 256) {
+    for (int i = threadIdx.x; i < rows_dst * S; i += DENSE_T) {
       const int r = i / S, sl = i - r * S;
       float v[4];
       for (int k = 0; k < 4; ++k) {
@@ -85,7 +94,7 @@ __global__ __launch_bounds__(256, 1) void dense_kernel(DenseArgs A) {
   }
   load_w(E_l, A.Ws, A.Ws ? A.attn : 0, 0, 16);
   load_w(E_l, A.W_final, A.W_final ? 1 : 0, 16, 16);
-  for (int i = threadIdx.x; i < 4 * DP; i += 256) {
+  for (int i = threadIdx.x; i < 4 * DP; i += DENSE_T) {
     const int g = i / DP, c = i - g * DP;
     float v = 0.f;
     if (c < d) {
@@ -99,128 +108,122 @@ __global__ __launch_bounds__(256, 1) void dense_kernel(DenseArgs A) {
   __syncthreads();
 
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int li = lane & 31, h = lane >> 5;
-  float4* tile = tiles + wv * 32 * S;
+  const int li = lane & 15, hq = lane >> 4;
+  float4* tile = tiles + wv * 16 * S;
 
-  // B fragment of the wave's staged tile: register m <- X[node li][k(h, m)]
+  // B fragment of the wave's staged tile: registers 4*ob..4*ob+3 <- X[node li][16*ob + 4*hq + (0..3)]
   auto read_frag = [&](float (&f)[KS]) {
 #pragma unroll
-    for (int jb = 0; jb < NB; ++jb)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 v = tile[sw<DP>(li, 8 * jb + 2 * q + h)];
-        f[16 * jb + 4 * q + 0] = v.x; f[16 * jb + 4 * q + 1] = v.y; f[16 * jb + 4 * q + 2] = v.z; f[16 * jb + 4 * q + 3] = v.w;
-      }
+    for (int ob = 0; ob < NB; ++ob) {
+      const float4 v = tile[sw<DP>(li, 4 * ob + hq)];
+      f[4 * ob + 0] = v.x; f[4 * ob + 1] = v.y; f[4 * ob + 2] = v.z; f[4 * ob + 3] = v.w;
+    }
   };
-  // acc += W[row0 + (0..31)][:] . frag     (one 32-row block of a weight image)
-  auto mma = [&](const float4* W_l, int row0, const float (&f)[KS], f32x16 acc) -> f32x16 {
+  // acc += W[row0 + (0..15)][:] . frag     (one 16-row block of a weight image)
+  auto mma = [&](const float4* W_l, int row0, const float (&f)[KS], f32x4 acc) -> f32x4 {
 #pragma unroll
-    for (int jb = 0; jb < NB; ++jb)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 a = W_l[sw<DP>(row0 + li, 8 * jb + 2 * q + h)];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, f[16 * jb + 4 * q + 0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, f[16 * jb + 4 * q + 1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, f[16 * jb + 4 * q + 2], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, f[16 * jb + 4 * q + 3], acc, 0, 0, 0);
-      }
+    for (int kb = 0; kb < NB; ++kb) {
+      const float4 a = W_l[sw<DP>(row0 + li, 4 * kb + hq)];
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, f[4 * kb + 0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, f[4 * kb + 1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, f[4 * kb + 2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, f[4 * kb + 3], acc, 0, 0, 0);
+    }
     return acc;
   };
-  // accumulator row index of register r in this lane: (r&3) + 8*(r>>2) + 4*h
-  auto bias_acc = [&](int g, int ob) -> f32x16 {
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = bias_l[g * DP + 32 * ob + (r & 3) + 8 * (r >> 2) + 4 * h];
+  // accumulator row of register r of block ob in this lane: 16*ob + 4*hq + r
+  auto bias_acc = [&](int g, int ob) -> f32x4 {
+    const float4 v = *reinterpret_cast<const float4*>(bias_l + g * DP + 16 * ob + 4 * hq);
+    f32x4 acc = {v.x, v.y, v.z, v.w};
     return acc;
   };
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-  for (int t = blockIdx.x * 4 + wv; t < A.n_tiles; t += gridDim.x * 4) {
-    const int64_t row0 = (int64_t)t * 32;
-    // ---- stage agg tile (coalesced float4 rows) -----------------------------------------------------------
+  for (int t = blockIdx.x * NW + wv; t < A.n_tiles; t += gridDim.x * NW) {
+    const int64_t row0 = (int64_t)t * 16;
+    // ---- issue both tile loads (agg rows: coalesced; old state: gathered rows) ---------------------------------
+    float4 va[16 * S / 64], vh[16 * S / 64];
+#pragma unroll
+    for (int it = 0; it < 16 * S / 64; ++it) {
+      const int e = it * 64 + lane, r = e / S, sl = e - r * S;
+      va[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      vh[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row0 + r < A.n && sl < A.ld4) {
+        va[it] = A.agg[(row0 + r) * A.ld4 + sl];
+        if (A.prev_idx) {
+          const int p = A.prev_idx[row0 + r];
+          if (p >= 0) vh[it] = A.hprev[(int64_t)p * A.ld4 + sl];
+        }
+      }
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int it = 0; it < 32 * S / 64; ++it) {
+    for (int it = 0; it < 16 * S / 64; ++it) {
       const int e = it * 64 + lane, r = e / S, sl = e - r * S;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row0 + r < A.n && sl < A.ld4) v = A.agg[(row0 + r) * A.ld4 + sl];
-      tile[sw<DP>(r, sl)] = v;
+      tile[sw<DP>(r, sl)] = va[it];
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     float fx[KS];
     read_frag(fx);
-
-    // ---- stage gathered old state (issue early; consumed after stage 1) -------------------------------------
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int it = 0; it < 32 * S / 64; ++it) {
+    for (int it = 0; it < 16 * S / 64; ++it) {
       const int e = it * 64 + lane, r = e / S, sl = e - r * S;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row0 + r < A.n && sl < A.ld4 && A.prev_idx) {
-        const int p = A.prev_idx[row0 + r];
-        if (p >= 0) v = A.hprev[(int64_t)p * A.ld4 + sl];
-      }
-      tile[sw<DP>(r, sl)] = v;
+      tile[sw<DP>(r, sl)] = vh[it];
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
+    float hf[KS];
+    read_frag(hf);
 
     // ---- stage 1: x = act(W_h agg)   (accumulators become the next B fragment) ---------------------------
     float xf[KS];
 #pragma unroll
     for (int ob = 0; ob < NB; ++ob) {
-      f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      acc = mma(Wh_l, 32 * ob, fx, acc);
+      f32x4 acc = mma(Wh_l, 16 * ob, fx, zero4);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
+      for (int r = 0; r < 4; ++r) {
         float v = acc[r];
         if (A.act == 1) v = fmaxf(v, 0.f);
-        else if (A.act == 2) v = tanhf(v);
-        xf[16 * ob + r] = v;
+        else if (A.act == 2) v = fast_tanh(v);
+        xf[4 * ob + r] = v;
       }
     }
-    float hf[KS];
-    read_frag(hf);
 
     // ---- GRU gates ([r; z; n] row blocks of weight_ih / weight_hh) -----------------------------------------
     float hn[KS];
 #pragma unroll
     for (int ob = 0; ob < NB; ++ob) {
-      f32x16 ar = bias_acc(0, ob);
-      ar = mma(Wih_l, 0 * DP + 32 * ob, xf, ar);
-      ar = mma(Whh_l, 0 * DP + 32 * ob, hf, ar);
-      f32x16 az = bias_acc(1, ob);
-      az = mma(Wih_l, 1 * DP + 32 * ob, xf, az);
-      az = mma(Whh_l, 1 * DP + 32 * ob, hf, az);
-      f32x16 ai = bias_acc(2, ob);
-      ai = mma(Wih_l, 2 * DP + 32 * ob, xf, ai);
-      f32x16 ah = bias_acc(3, ob);
-      ah = mma(Whh_l, 2 * DP + 32 * ob, hf, ah);
+      f32x4 ar = bias_acc(0, ob), az = bias_acc(1, ob), ai = bias_acc(2, ob), ah = bias_acc(3, ob);
+      ar = mma(Wih_l, 0 * DP + 16 * ob, xf, ar);
+      az = mma(Wih_l, 1 * DP + 16 * ob, xf, az);
+      ai = mma(Wih_l, 2 * DP + 16 * ob, xf, ai);
+      ah = mma(Whh_l, 2 * DP + 16 * ob, hf, ah);
+      ar = mma(Whh_l, 0 * DP + 16 * ob, hf, ar);
+      az = mma(Whh_l, 1 * DP + 16 * ob, hf, az);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float rg = sigmoidf_(ar[r]), zg = sigmoidf_(az[r]);
-        const float ng = tanhf(ai[r] + rg * ah[r]);
-        hn[16 * ob + r] = (1.0f - zg) * ng + zg * hf[16 * ob + r];
+      for (int r = 0; r < 4; ++r) {
+        const float rg = fast_sigmoid(ar[r]), zg = fast_sigmoid(az[r]);
+        const float ng = fast_tanh(ai[r] + rg * ah[r]);
+        hn[4 * ob + r] = (1.0f - zg) * ng + zg * hf[4 * ob + r];
       }
     }
 
-    // ---- projections of the new state: a_s (next layer) and score (last layer) ----------------------------------
-    if (A.Ws || A.W_final) {
-      f32x16 ae = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      ae = mma(E_l, 0, hn, ae);
-      const int64_t node = row0 + li;
-      if (node < A.n) {
-        if (A.Ws) {   // rows e = (r&3) + 8*(r>>2) + 4h: e in [4h, 4h+4) are regs 0..3, [8+4h, 8+4h+4) regs 4..7
-          float4* out = reinterpret_cast<float4*>(A.a_s_out + node * A.ap);
-          if (4 * h < A.ap) out[h] = make_float4(ae[0], ae[1], ae[2], ae[3]);
-          if (8 + 4 * h < A.ap) out[2 + h] = make_float4(ae[4], ae[5], ae[6], ae[7]);
-        }
-        if (A.W_final && h == 0) {   // row 16 = reg 8 of half 0
-          const int b = A.nodes[2 * node], e = A.nodes[2 * node + 1];
-          A.scores[(int64_t)b * A.n_ent + e] = ae[8];
-        }
+    // ---- projections of the new state: a_s (next layer) or score (last layer) ----------------------------------
+    const int64_t node = row0 + li;
+    if (A.Ws) {       // rows e = 4*hq + r of block 0
+      const f32x4 ae = mma(E_l, 0, hn, zero4);
+      if (node < A.n && 4 * hq < A.ap)
+        reinterpret_cast<float4*>(A.a_s_out + node * A.ap)[hq] = make_float4(ae[0], ae[1], ae[2], ae[3]);
+    }
+    if (A.W_final) {  // row 16 = register 0 of quarter 0 of block 1
+      const f32x4 ae = mma(E_l, 16, hn, zero4);
+      if (node < A.n && hq == 0) {
+        const int b = A.nodes[2 * node], e = A.nodes[2 * node + 1];
+        A.scores[(int64_t)b * A.n_ent + e] = ae[0];
       }
     }
 
@@ -228,15 +231,12 @@ __global__ __launch_bounds__(256, 1) void dense_kernel(DenseArgs A) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int jb = 0; jb < NB; ++jb)
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        tile[sw<DP>(li, 8 * jb + 2 * q + h)] =
-            make_float4(hn[16 * jb + 4 * q + 0], hn[16 * jb + 4 * q + 1], hn[16 * jb + 4 * q + 2], hn[16 * jb + 4 * q + 3]);
+    for (int ob = 0; ob < NB; ++ob)
+      tile[sw<DP>(li, 4 * ob + hq)] = make_float4(hn[4 * ob + 0], hn[4 * ob + 1], hn[4 * ob + 2], hn[4 * ob + 3]);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int it = 0; it < 32 * S / 64; ++it) {
+    for (int it = 0; it < 16 * S / 64; ++it) {
       const int e = it * 64 + lane, r = e / S, sl = e - r * S;
       if (row0 + r < A.n && sl < A.ld4) A.hidden_out[(row0 + r) * A.ld4 + sl] = tile[sw<DP>(r, sl)];
     }
@@ -245,11 +245,11 @@ __global__ __launch_bounds__(256, 1) void dense_kernel(DenseArgs A) {
 
 template <int NB>
 int launch(const DenseArgs& A, hipStream_t s) {
-  constexpr int DP = 32 * NB, S = DP / 4;
-  const size_t lds = (size_t)(DP * S + 6 * DP * S + 32 * S) * sizeof(float4) + 4 * DP * sizeof(float) + (size_t)4 * 32 * S * sizeof(float4);
+  constexpr int DP = 16 * NB, S = DP / 4, NW = DENSE_T / 64;
+  const size_t lds = (size_t)(DP * S + 6 * DP * S + 32 * S) * sizeof(float4) + 4 * DP * sizeof(float) + (size_t)NW * 16 * S * sizeof(float4);
   RG_HIP(hipFuncSetAttribute((const void*)dense_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const int grid = (int)std::min<int64_t>(rg::ceil_div(A.n_tiles, 4), 256);
-  hipLaunchKernelGGL(dense_kernel<NB>, dim3(grid), dim3(256), lds, s, A);
+  const int grid = (int)std::min<int64_t>(rg::ceil_div(A.n_tiles, NW), 256);
+  hipLaunchKernelGGL(dense_kernel<NB>, dim3(grid), dim3(DENSE_T), lds, s, A);
   RG_LAUNCH_CHECK();
   return 0;
 }
@@ -281,7 +281,7 @@ extern "C" int rg_dense_fwd(int64_t n, int32_t d, int32_t ld, const float* agg, 
   A.Ws = Ws_next; A.attn = attn_dim; A.ap = ap; A.a_s_out = a_s_out;
   A.W_final = W_final; A.nodes = nodes; A.n_ent = n_ent; A.scores = scores_all;
   A.hidden_out = (float4*)hidden_out; A.act = act;
-  A.n_tiles = (int)rg::ceil_div(n, 32);
+  A.n_tiles = (int)rg::ceil_div(n, 16);
   hipStream_t s = (hipStream_t)stream;
-  return d <= 32 ? launch<1>(A, s) : launch<2>(A, s);
+  return d <= 32 ? launch<2>(A, s) : launch<4>(A, s);
 }

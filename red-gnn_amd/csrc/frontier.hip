@@ -32,25 +32,35 @@ __global__ void reset_nodes_kernel(const int32_t* __restrict__ nodes, int64_t n,
 }
 
 // ---- one hop on the entity-major bitmap: new[t] = OR over in-edges (h -> t) of old[h] --------------
-// One wave per entity t.  WL lanes span the B/32 words of a row, 64/WL lanes stride over in-edges.
-__global__ __launch_bounds__(256) void hop_or_kernel(const int32_t* __restrict__ in_ptr, const int2* __restrict__ in_hr,
-                                                     const uint32_t* __restrict__ oldT, uint32_t* __restrict__ newT,
-                                                     int n_ent, int BW, int WL) {
+// One wave per virtual row of the CSR-by-tail (<= 128 in-edges; a hub of in-degree 17k is 133 waves, not
+// one 17k-long chain of dependent loads).  WL lanes span the B/32 words of a bitmap row, 64/WL lanes
+// stride over the in-edges, 4 independent loads in flight each; rows are merged with atomicOr
+// (order-free), newT is zeroed by the caller.
+__global__ __launch_bounds__(256) void hop_or_kernel(const int4* __restrict__ vrows, int n_vrows,
+                                                     const int2* __restrict__ in_hr, const uint32_t* __restrict__ oldT,
+                                                     uint32_t* __restrict__ newT, int BW, int WL) {
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
-  if (wave >= n_ent) return;
-  const int t = wave;
+  if (wave >= n_vrows) return;
+  const int4 row = vrows[wave];
+  const int t = row.x, beg = row.y, end = row.y + row.z;
   const int wl = lane & (WL - 1);
   const int el = lane / WL, EL = 64 / WL;
-  const int beg = in_ptr[t], end = in_ptr[t + 1];
   for (int w0 = 0; w0 < BW; w0 += WL) {
     const int w = w0 + wl;
     uint32_t acc = 0;
     if (w < BW) {
-      for (int j = beg + el; j < end; j += EL) acc |= oldT[(int64_t)in_hr[j].x * BW + w];
+      for (int j = beg + el; j < end; j += 4 * EL) {
+        int hh[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) hh[u] = (j + u * EL < end) ? in_hr[j + u * EL].x : -1;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (hh[u] >= 0) acc |= oldT[(int64_t)hh[u] * BW + w];
+      }
     }
     for (int o = WL; o < 64; o <<= 1) acc |= __shfl_xor(acc, o, 64);
-    if (el == 0 && w < BW) newT[(int64_t)t * BW + w] = acc;
+    if (el == 0 && w < BW && acc) atomicOr(&newT[(int64_t)t * BW + w], acc);
   }
 }
 
@@ -293,8 +303,9 @@ int rg_frontier_expand(rg_frontier* f, const rg_graph* g, int64_t* counts_host, 
   hipLaunchKernelGGL(count_edges_kernel, dim3(rg::ceil_div((int64_t)f->n_ent * f->BW, 256)), dim3(256), 0, s, g->out_ptr,
                      oldT, f->n_ent, f->BW, (unsigned long long*)&f->counters[2]);
   RG_LAUNCH_CHECK();
-  hipLaunchKernelGGL(hop_or_kernel, dim3(rg::ceil_div(f->n_ent, 4)), dim3(256), 0, s, g->in_ptr, g->in_hr, oldT, newT,
-                     f->n_ent, f->BW, WL);
+  RG_HIP(hipMemsetAsync(newT, 0, (size_t)f->n_ent * f->BW * 4, s));
+  hipLaunchKernelGGL(hop_or_kernel, dim3(rg::ceil_div(g->in_vr.n, 4)), dim3(256), 0, s, g->in_vr.rows, g->in_vr.n, g->in_hr,
+                     oldT, newT, f->BW, WL);
   RG_LAUNCH_CHECK();
   const int64_t n_old = f->n_nodes[f->level % f->n_levels];
   f->tcur ^= 1;
