@@ -21,6 +21,9 @@ def _require_gpu(device):
         raise _lib.NativeError("red_gnn_amd runs on an MI355X (device 'cuda'); got device %r. "
                                "There is no CPU path in the product — the CPU restatement lives in oracle/ for tests only."
                                % (device,))
+    if not torch.cuda.is_available():
+        raise _lib.NativeError("red_gnn_amd needs an MI355X: no ROCm device is visible to this process. The HIP path has "
+                               "no CPU fallback (the CPU restatement in oracle/ is test infrastructure only).")
     return device
 
 

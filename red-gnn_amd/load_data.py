@@ -14,7 +14,7 @@ from collections import defaultdict
 import numpy as np
 import torch
 
-from .engine import Frontier, Graph
+from .engine import Frontier, Graph, _require_gpu
 
 
 class DataLoader:
@@ -37,7 +37,7 @@ class DataLoader:
         self.valid_data = self.double_triple(self.valid_triple)
         self.test_data = self.double_triple(self.test_triple)
 
-        self.graph = self.tgraph = None
+        self._graph = self._tgraph = None
         self.load_graph(self.fact_triple)                                               # :43
         self.load_test_graph(np.concatenate([self.fact_triple, self.train_triple], 0))  # :44
 
@@ -85,17 +85,31 @@ class DataLoader:
         return np.concatenate([triples, inv], 0)
 
     # ---- graphs (load_data.py:76-89): inverse + identity rows are added by rg_graph_create -----------
+    # The device graphs are built on first use, so the host-side logic of this class (parsing, filters,
+    # queries, batches) also runs where there is no GPU.
     def load_graph(self, base_triples):
-        if self.graph is not None:
-            self.graph.close()
-        self.graph = Graph(self.n_ent, self.n_rel, base_triples, add_inverse=True, device=self.device)
-        self.n_fact = self.graph.n_fact
+        if self._graph is not None:
+            self._graph.close()
+        self._graph, self._graph_base = None, np.asarray(base_triples, dtype=np.int64).reshape(-1, 3)
+        self.n_fact = 2 * len(self._graph_base) + self.n_ent
 
     def load_test_graph(self, base_triples):
-        if self.tgraph is not None:
-            self.tgraph.close()
-        self.tgraph = Graph(self.n_ent, self.n_rel, base_triples, add_inverse=True, device=self.device)
-        self.tn_fact = self.tgraph.n_fact
+        if self._tgraph is not None:
+            self._tgraph.close()
+        self._tgraph, self._tgraph_base = None, np.asarray(base_triples, dtype=np.int64).reshape(-1, 3)
+        self.tn_fact = 2 * len(self._tgraph_base) + self.n_ent
+
+    @property
+    def graph(self):
+        if self._graph is None:
+            self._graph = Graph(self.n_ent, self.n_rel, self._graph_base, add_inverse=True, device=self.device)
+        return self._graph
+
+    @property
+    def tgraph(self):
+        if self._tgraph is None:
+            self._tgraph = Graph(self.n_ent, self.n_rel, self._tgraph_base, add_inverse=True, device=self.device)
+        return self._tgraph
 
     def graph_for(self, mode):
         """load_data.py:107-112: 'train' walks the fact graph, anything else facts + train."""
@@ -115,6 +129,7 @@ class DataLoader:
         """Same contract as the reference: nodes [N,2] (batch_idx, entity) ->
         (tail_nodes LongTensor [N',2] sorted, sampled_edges LongTensor [E,6], old_nodes_new_idx LongTensor [N]),
         on the device.  Edges come destination-segmented (the reference's order is fact-row major)."""
+        _require_gpu(self.device)
         nodes_t = torch.as_tensor(np.asarray(nodes) if not torch.is_tensor(nodes) else nodes)
         nodes_t = nodes_t.to(device=self.device, dtype=torch.int32).contiguous()
         n_batch = int(nodes_t[:, 0].max().item()) + 1 if nodes_t.numel() else 1
@@ -149,7 +164,7 @@ class DataLoader:
         rels = np.array([query[i][1] for i in batch_idx])
         ans = [np.sort(np.asarray(answer[i])) for i in batch_idx]       # np.nonzero order of base_model.py / utils.py:12-13
         fil = [np.asarray(self.filters[(int(s), int(r))]) for s, r in zip(subs, rels)]
-        to_dev = lambda a: torch.as_tensor(a, dtype=torch.int32, device=self.device)
+        to_dev = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.int32).to(self.device)
         ptr = lambda lists: np.concatenate([[0], np.cumsum([len(x) for x in lists])])
         cat = lambda lists: np.concatenate(lists) if len(lists) else np.zeros(0, np.int64)
         return subs, rels, to_dev(ptr(ans)), to_dev(cat(ans)), to_dev(ptr(fil)), to_dev(cat(fil))

@@ -1,0 +1,171 @@
+"""CPU-only checks (-m "not gpu"): the C-ABI library loads and exports every symbol the header declares,
+the host logic of the loader mirrors the reference's parsing, the product refuses to run without a GPU,
+and the query-sharding collectives work under gloo with world_size 2.  No kernel is launched here."""
+import os
+import re
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import redgnn_oracle as orc
+from tests import _util as U
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    text = open(os.path.join(ROOT, "include", "redgnn.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rg_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_header_symbol():
+    from red_gnn_amd import _lib
+    lib = _lib.lib()
+    syms = _header_symbols()
+    assert len(syms) >= 18
+    for s in syms:
+        assert hasattr(lib, s), "libredgnn.so does not export %s" % s
+    assert sorted(_lib.SYMBOLS) == syms            # the ctypes binding covers exactly the header
+    assert lib.rg_version() >= 1
+    assert lib.rg_frontier_workspace_bytes(100, 4, 2) > 0
+    assert lib.rg_frontier_workspace_bytes(100, 4, 1) == 0      # needs >= 2 levels
+
+
+def test_argument_errors_are_reported_not_fatal():
+    """Error contract of the ABI: non-zero return + rg_last_error(), checked before any device work."""
+    import ctypes as C
+    from red_gnn_amd import _lib
+    lib = _lib.lib()
+    h = C.c_void_p()
+    assert lib.rg_graph_create(0, 3, None, 0, 1, C.byref(h)) != 0
+    assert b"n_ent" in lib.rg_last_error()
+    bad = np.array([[0, 0, 99]], dtype=np.int32)
+    assert lib.rg_graph_create(10, 3, _lib.ptr(bad), 1, 1, C.byref(h)) != 0
+    assert b"out of range" in lib.rg_last_error()
+    assert lib.rg_frontier_create(1 << 20, 1 << 12, 2, None, 0, C.byref(h)) != 0     # B*n_ent >= 2^31
+    assert b"int32" in lib.rg_last_error()
+    assert lib.rg_dense_fwd_supported(64, 5) == 1 and lib.rg_dense_fwd_supported(128, 5) == 0
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
+def test_product_fails_loudly_without_gpu():
+    from red_gnn_amd import _lib
+    from red_gnn_amd.load_data import DataLoader
+    from red_gnn_amd.models import RED_GNN_trans
+    ids = U.load("tiny_fwd.npz")
+    loader = DataLoader(ids=ids, verbose=False)
+
+    class P:
+        n_layer, hidden_dim, attn_dim, n_rel, act, dropout = 2, 16, 3, loader.n_rel, "relu", 0.0
+
+    model = RED_GNN_trans(P, loader)
+    with pytest.raises(_lib.NativeError):
+        model(ids["subs"], ids["rels"], mode="test")          # CPU parameters: refused, no silent fallback
+    with pytest.raises(_lib.NativeError):
+        loader.get_neighbors(np.array([[0, 1]]), mode="test")
+
+
+def test_loader_text_and_ids_agree_and_match_reference_split():
+    """Text parsing (load_data.py:11-35,58-67) vs the id arrays the reference's own parser produced."""
+    from red_gnn_amd.load_data import DataLoader
+    from red_gnn_amd.synthetic import make_synthetic_kg, write_task_dir
+    ids = U.load("tiny_fwd.npz")       # ids as parsed by the REFERENCE loader from the same generated text
+    kg = make_synthetic_kg(50, 4, 300, seed=7)
+    with tempfile.TemporaryDirectory() as td:
+        write_task_dir(kg, td)
+        a = DataLoader(td, verbose=False)
+    b = DataLoader(ids=ids, verbose=False)
+    for name in ("fact_triple", "train_triple", "valid_triple", "test_triple", "fact_data", "train_data"):
+        assert np.array_equal(getattr(a, name), getattr(b, name)), name
+    assert np.array_equal(a.fact_triple, ids["facts"]) and np.array_equal(a.test_triple, ids["test"])
+    assert (a.n_ent, a.n_rel, a.n_train, a.n_valid, a.n_test) == (b.n_ent, b.n_rel, b.n_train, b.n_valid, b.n_test)
+    assert a.filters == b.filters and a.valid_q == b.valid_q and a.test_q == b.test_q
+    assert a.n_fact == 2 * len(ids["facts"]) + a.n_ent and a.tn_fact == U.oracle_graph(ids, "test").n_fact
+    # the fixture's first four test queries / labels / filters are what get_batch builds
+    subs, rels, objs = b.get_batch(np.arange(4), data="test")
+    assert np.array_equal(subs, ids["subs"]) and np.array_equal(rels, ids["rels"])
+    assert np.array_equal(objs.astype(np.uint8), ids["labels"])
+    for i in range(4):
+        f = np.zeros(b.n_ent, np.uint8)
+        f[b.filters[(int(subs[i]), int(rels[i]))]] = 1
+        assert np.array_equal(f, ids["filters"][i])
+    # inverse triples (load_data.py:69-74) and the 3:1 re-split (load_data.py:152-164)
+    assert np.array_equal(b.train_data, orc.double_triple(ids["train"], b.n_rel))
+    np.random.seed(0)
+    n_all = len(ids["facts"]) + len(ids["train"])
+    b.shuffle_train()
+    assert b.n_train == 2 * (n_all - n_all * 3 // 4) and b.n_fact == 2 * (n_all * 3 // 4) + b.n_ent
+
+
+def test_synthetic_generator_is_deterministic_and_shaped():
+    from red_gnn_amd.synthetic import SHAPES, make_synthetic_kg
+    a, b = make_synthetic_kg(2000, 11, 9000, seed=1234), make_synthetic_kg(2000, 11, 9000, seed=1234)
+    for n in ("facts", "train", "valid", "test"):
+        assert np.array_equal(getattr(a, n), getattr(b, n))
+    assert len(a.facts) + len(a.train) == 9000 and len(a.facts) == 6750 and len(a.valid) == len(a.test) == 450
+    allt = np.concatenate([a.facts, a.train, a.valid, a.test])
+    assert len(np.unique(allt, axis=0)) == len(allt) and np.all(allt[:, 0] != allt[:, 2])
+    indeg = np.bincount(allt[:, 2], minlength=2000)
+    assert indeg.max() > 20 * indeg.mean()                      # hubs, as SURVEY.md §8(d) asks
+    assert set(SHAPES) == {"C2", "C3", "C4", "C5"}
+
+
+def test_shard_helpers():
+    from red_gnn_amd.sharding import shard_by_cost, shard_slice
+    for n, w in ((10, 3), (8, 8), (5, 8), (1024, 4)):
+        sl = [shard_slice(n, w, r) for r in range(w)]
+        assert sl[0][0] == 0 and sl[-1][1] == n and all(sl[i][1] == sl[i + 1][0] for i in range(w - 1))
+        assert max(b - a for a, b in sl) - min(b - a for a, b in sl) <= 1
+    parts = shard_by_cost([9, 1, 1, 1, 8, 2, 2, 2], 2)
+    assert sorted(sum(parts, [])) == list(range(8))
+    assert abs(sum([9, 1, 1, 1, 8, 2, 2, 2][i] for i in parts[0]) - 13) <= 1
+
+
+def _gloo_worker(rank, world, port, ret):
+    import torch.distributed as dist
+    from red_gnn_amd.sharding import allreduce_gradients, gather_scores, reduce_metrics, shard_slice
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        fx = U.load("tiny_fwd.npz")
+        g = U.oracle_graph(fx, "test")
+        p = U.params_of(fx)
+        lo, hi = shard_slice(len(fx["subs"]), world, rank)
+        # each rank runs ITS queries only (the oracle stands in for the HIP path on this CPU-only box)
+        local = orc.forward(p, g, fx["subs"][lo:hi], fx["rels"][lo:hi], int(fx["cfg"][0]), act=str(fx["act"]))
+        full = gather_scores(local, dist)
+        ranks = np.array(orc.cal_ranks(local.numpy(), fx["labels"][lo:hi].astype(float), fx["filters"][lo:hi].astype(float)))
+        sums = torch.tensor([(1.0 / ranks).sum(), (ranks <= 1).sum(), (ranks <= 10).sum(), float(len(ranks))], dtype=torch.float64)
+        tot = reduce_metrics(sums, dist)
+        w = torch.nn.Linear(3, 2)
+        w.weight.grad = torch.full_like(w.weight, float(rank + 1))
+        w.bias.grad = torch.full_like(w.bias, 10.0 * (rank + 1))
+        allreduce_gradients(list(w.parameters()), dist)
+        if rank == 0:
+            ret["full"], ret["tot"] = full.numpy(), tot.numpy()
+            ret["gw"], ret["gb"] = w.weight.grad.numpy().copy(), w.bias.grad.numpy().copy()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_query_sharding_world_size_2_gloo():
+    """N>1 path: queries sharded over 2 ranks, scores all-gathered, metric sums and gradients all-reduced."""
+    import torch.multiprocessing as mp
+    port = 29500 + os.getpid() % 2000
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_gloo_worker, args=(2, port, ret), nprocs=2, join=True)
+        fx = U.load("tiny_fwd.npz")
+        np.testing.assert_allclose(ret["full"], fx["scores"], rtol=1e-4, atol=1e-5)      # sharded == unsharded reference
+        ranks = fx["ranks"]
+        np.testing.assert_allclose(ret["tot"], [(1.0 / ranks).sum(), (ranks <= 1).sum(), (ranks <= 10).sum(), len(ranks)])
+        assert np.all(ret["gw"] == 3.0) and np.all(ret["gb"] == 30.0)
+
+
+def test_bench_byte_model():
+    import bench
+    assert bench.algorithmic_bytes(10, 3, 64) == 10 * 272 + 3 * 256
+    assert bench.algorithmic_bytes(1, 1, 128) == 528 + 512
