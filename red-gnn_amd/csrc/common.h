@@ -67,6 +67,9 @@ struct rg_graph {
   // CSR by tail: in_ptr[n_ent+1], in_hr[n_fact] = {head, rel}
   int32_t* in_ptr = nullptr;
   int2* in_hr = nullptr;
+  // packed CSR-by-tail entries (rel << 20 | head), present when n_ent <= 2^20 and 2*n_rel+1 <= 2^12:
+  // halves the structure bytes every query streams through its XCD's L2
+  uint32_t* in_pk = nullptr;
   rg_vrows in_vr, out_vr;
 };
 

@@ -12,21 +12,22 @@
 //           acc   += alpha * (hidden[s] + rela[r])
 //       agg[o] = acc       (or a partial row when t is a hub cut into segments; combined in order below)
 //
-// Mapping (wave64):
-//   * a wave grabs 64 consecutive work items from an in-order queue; each lane tests one item
-//     (visited bit + rank), survivors are compacted through a wave-private LDS strip;
-//   * a survivor is owned by a group of G lanes, G*4 >= d floats, so a row is one coalesced float4
-//     per lane (d=64: 16 lanes x 16 B = 256 B per row, 4 destinations per wave);
+// Mapping (wave64), 1024-thread workgroups at <= 64 VGPRs (32 waves per CU hide the gather latency):
+//   * a destination item is owned by a group of G lanes, G*4 >= d floats, so a row is one coalesced
+//     float4 per lane (d=64: 16 lanes x 16 B = 256 B per row, 4 destinations per wave);
 //   * phase 1 runs lane-per-candidate (index math + attention scalar, G candidates at a time);
 //     surviving edges are compacted into a per-group LDS strip; phase 2 runs group-per-edge
 //     (row gather + FMA), four edges in flight per group;
 //   * virtual rows are sorted by length, so the groups of a wave have equal trip counts, and a hub
 //     of in-degree 17k is 133 independent items instead of one 17k-long serial loop;
-//   * work space is query-major; XCD x serves the x-th eighth of it from its own queue (in order),
-//     so the hidden slab of the queries being processed (<= n_ent*d*4 B each) stays in that XCD's
-//     4 MiB L2 while every destination of the query gathers from it.  Queues are only a speed
-//     device: a wave that finds its queue empty steals from the others, so every item is processed
-//     whatever the workgroup placement.
+//   * the work space is query-major; XCD x (HW_REG_XCC_ID) serves the x-th eighth of it from its own
+//     in-order queue, one block step at a time: a 16-wave workgroup takes 64 consecutive items (DENSE:
+//     one per lane group; SPARSE: 1024, one lane tests one item and survivors are compacted), the
+//     next ticket is prefetched while the step runs.  An XCD's 64 resident workgroups therefore span
+//     at most 4096 consecutive items - a third of ONE query - whose hidden slab (<= n_ent*d*4 B)
+//     stays in that XCD's 4 MiB L2 while its destinations gather from it.  Queues only steer speed: a
+//     workgroup that finds its queue dry steals from the others, every item is processed once under
+//     any placement.
 // rela / a_r / w_alpha live in LDS.  Sums run in CSR order: bitwise reproducible.
 #include "common.h"
 
@@ -38,6 +39,7 @@ struct FwdArgs {
   int32_t n_slots;
   const int4* vrows;
   const int2* in_hr;
+  const uint32_t* in_pk;
   const int2* bm_old;
   const int2* bm_new;
   int W;
@@ -54,20 +56,24 @@ struct FwdArgs {
   int rela_in_lds;
   float4* agg;
   float4* partial;
-  int32_t* queues;  // [8], zeroed before the launch
+  int32_t* queues;  // [8] item offsets inside each eighth, zeroed before the launch
 };
 
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
-template <int G, int AP4, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void layer_fwd_kernel(FwdArgs A) {
+constexpr int FWD_BLOCK = 512;   // 3 workgroups per CU = 24 waves at <= 80 VGPRs (no spills)
+
+template <int G, int AP4, bool PACKED, bool DENSE, bool RELA_LDS>
+__global__ __launch_bounds__(FWD_BLOCK, 6) void layer_fwd_kernel(FwdArgs A) {
   extern __shared__ float4 lds[];
+  constexpr int BLOCK = FWD_BLOCK;
   constexpr int GW = 64 / G;                             // destination groups per wave
+  constexpr int WPB = BLOCK / 64;
   float4* stage = lds;                                   // [BLOCK] edge tuples {s, r, alpha, -}
-  int4* recs = reinterpret_cast<int4*>(lds + BLOCK);     // [BLOCK] surviving items {beg, len, b, out}
-  float4* ar_l = lds + 2 * BLOCK;                        // [n_rela_rows][AP4]
+  float4* ar_l = lds + BLOCK;                            // [n_rela_rows][AP4]
   float4* w_l = ar_l + A.n_rela_rows * AP4;              // [AP4]
   float4* rela_l = w_l + AP4;                            // [n_rela_rows][G] (optional)
+  int4* recs = reinterpret_cast<int4*>(rela_l + (RELA_LDS ? A.n_rela_rows * G : 0));   // [BLOCK] (SPARSE only)
 
   for (int i = threadIdx.x; i < A.n_rela_rows * AP4; i += BLOCK) ar_l[i] = A.a_r[i];
   if (threadIdx.x < AP4) {
@@ -78,7 +84,7 @@ __global__ __launch_bounds__(BLOCK) void layer_fwd_kernel(FwdArgs A) {
     }
     w_l[threadIdx.x] = make_float4(w[0], w[1], w[2], w[3]);
   }
-  if (A.rela_in_lds) {
+  if constexpr (RELA_LDS) {
     for (int i = threadIdx.x; i < A.n_rela_rows * G; i += BLOCK) {
       const int r = i / G, c = i - r * G;
       rela_l[i] = c < A.ld4 ? A.rela[(int64_t)r * A.ld4 + c] : f4zero();
@@ -89,132 +95,163 @@ __global__ __launch_bounds__(BLOCK) void layer_fwd_kernel(FwdArgs A) {
 
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int lane_g = lane & (G - 1), gi_w = lane / G;
-  int4* my_recs = recs + wv * 64;
   float4* my_stage = stage + wv * 64 + gi_w * G;
   const int gshift = lane & ~(G - 1);
   const unsigned long long gmask = G == 64 ? ~0ull : ((1ull << G) - 1ull);
   const bool row_lane = lane_g < A.ld4;
+  const int lane_c = row_lane ? lane_g : A.ld4 - 1;   // loads never branch: idle lanes re-read the last float4
 
-  // HW_REG_XCC_ID (id 20, 4 bits): which XCD this workgroup runs on.  Speed only.
-  int q = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7;
-  int n_dry = 0;
-
-  for (;;) {
-    // ---- grab 64 consecutive items from queue q (steal from the next queue when it is dry) --------
-    int64_t qs = 0, ql = 0;
-    int off = 0;
-    for (;;) {
-      qs = A.n_items * q / 8;
-      ql = A.n_items * (q + 1) / 8 - qs;
-      off = 0;
-      if (lane == 0) off = atomicAdd(&A.queues[q], 64);
-      off = __builtin_amdgcn_readfirstlane(off);
-      if (off < ql) break;
-      q = (q + 1) & 7;
-      if (++n_dry == 8) return;      // every queue seen dry: all items are taken
+  // one destination item: sum over its candidate in-edges [beg, end) for query b
+  auto run_item = [&](int beg, int end, int b) -> float4 {
+    const float4* aq_p = A.a_q + (int64_t)b * AP4;
+    float4 aq[AP4 <= 2 ? AP4 : 1];
+    if constexpr (AP4 <= 2) {
+#pragma unroll
+      for (int k = 0; k < AP4; ++k) aq[k] = aq_p[k];
     }
+    const int2* bm_row = A.bm_old + (int64_t)b * A.W;
+    float4 acc = f4zero();
+    for (int c0 = beg; c0 < end; c0 += G) {
+      // ---- phase 1: one candidate in-edge per lane ---------------------------------------------
+      const int c = c0 + lane_g;
+      bool valid = c < end;
+      int s = 0, r = 0;
+      float alpha = 0.f;
+      if (valid) {
+        int hd;
+        if constexpr (PACKED) { const uint32_t pk = A.in_pk[c]; hd = pk & 0xFFFFF; r = pk >> 20; }
+        else { const int2 hr = A.in_hr[c]; hd = hr.x; r = hr.y; }
+        const int2 wp = bm_row[hd >> 5];
+        const uint32_t word = (uint32_t)wp.x, bit = hd & 31;
+        valid = (word >> bit) & 1u;
+        if (valid) {
+          s = wp.y + __popc(word & ((1u << bit) - 1u));
+          float z = b_alpha;
+#pragma unroll
+          for (int k = 0; k < AP4; ++k) {
+            const float4 as = A.a_s[(int64_t)s * AP4 + k];
+            const float4 ar = ar_l[r * AP4 + k];
+            const float4 w = w_l[k];
+            float4 q;
+            if constexpr (AP4 <= 2) q = aq[k]; else q = aq_p[k];
+            z = fmaf(w.x, fmaxf(as.x + ar.x + q.x, 0.f), z);
+            z = fmaf(w.y, fmaxf(as.y + ar.y + q.y, 0.f), z);
+            z = fmaf(w.z, fmaxf(as.z + ar.z + q.z, 0.f), z);
+            z = fmaf(w.w, fmaxf(as.w + ar.w + q.w, 0.f), z);
+          }
+          alpha = __frcp_rn(1.0f + __expf(-z));
+        }
+      }
+      const unsigned long long m = (__ballot(valid) >> gshift) & gmask;
+      const int cnt = __popcll(m);
+      const int pos = __popcll(m & ((1ull << lane_g) - 1ull));
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // previous round's reads are done
+      __builtin_amdgcn_wave_barrier();
+      if (lane_g >= cnt) my_stage[lane_g] = f4zero();          // pad tuples: alpha = 0, row 0
+      if (valid) my_stage[pos] = make_float4(__int_as_float(s), __int_as_float(r), alpha, 0.f);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
 
-    // ---- filter: one item per lane -----------------------------------------------------------------
-    bool ok = (int64_t)off + lane < ql;
-    int4 rec = make_int4(0, 0, 0, 0);
-    if (ok) {
-      const int64_t item = qs + off + lane;
-      const int b = (int)(item / A.n_vrows);
-      const int vr = (int)(item - (int64_t)b * A.n_vrows);
-      const int4 row = A.vrows[vr];
-      const int2 wp = A.bm_new[(int64_t)b * A.W + (row.x >> 5)];
-      const uint32_t word = (uint32_t)wp.x, bit = row.x & 31;
-      ok = (word >> bit) & 1u;
-      if (ok) {
-        const int o = wp.y + __popc(word & ((1u << bit) - 1u));
-        rec = make_int4(row.y, row.z, b, row.w < 0 ? o : -(b * A.n_slots + row.w) - 1);
+      // ---- phase 2: one edge per group step, 4 row gathers in flight ---------------------------
+      for (int k = 0; k < cnt; k += 4) {
+        float4 tp[4], hv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) tp[u] = my_stage[k + u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          hv[u] = A.hidden[(int64_t)__float_as_int(tp[u].x) * A.ld4 + lane_c];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int ru = __float_as_int(tp[u].y);
+          float4 rv;
+          if constexpr (RELA_LDS) rv = rela_l[ru * G + lane_g];
+          else rv = A.rela[(int64_t)ru * A.ld4 + lane_c];
+          const float al = tp[u].z;
+          acc.x = fmaf(al, hv[u].x + rv.x, acc.x);
+          acc.y = fmaf(al, hv[u].y + rv.y, acc.y);
+          acc.z = fmaf(al, hv[u].z + rv.z, acc.z);
+          acc.w = fmaf(al, hv[u].w + rv.w, acc.w);
+        }
       }
     }
-    const unsigned long long surv = __ballot(ok);
-    const int n_surv = __popcll(surv);
-    if (n_surv == 0) continue;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    if (ok) my_recs[__popcll(surv & ((1ull << lane) - 1ull))] = rec;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
+    return acc;
+  };
+  auto store_row = [&](int out, float4 acc) {
+    if (!row_lane) return;
+    if (out >= 0) A.agg[(int64_t)out * A.ld4 + lane_g] = acc;
+    else A.partial[(int64_t)(-out - 1) * A.ld4 + lane_g] = acc;
+  };
+  // (b, vrow) -> {beg, len, b, out} if (b, entity) is in the new frontier
+  auto test_item = [&](int b, int vr, int4& rec) -> bool {
+    const int4 row = A.vrows[vr];
+    const int2 wp = A.bm_new[(int64_t)b * A.W + (row.x >> 5)];
+    const uint32_t word = (uint32_t)wp.x, bit = row.x & 31;
+    if (!((word >> bit) & 1u)) return false;
+    const int o = wp.y + __popc(word & ((1u << bit) - 1u));
+    rec = make_int4(row.y, row.z, b, row.w < 0 ? o : -(b * A.n_slots + row.w) - 1);
+    return true;
+  };
 
-    // ---- survivors, GW at a time: one per lane group ---------------------------------------------------
-    for (int j = 0; j < n_surv; j += GW) {
-      const bool live = j + gi_w < n_surv;
-      const int4 R = live ? my_recs[j + gi_w] : make_int4(0, 0, 0, 0);
-      const int beg = R.x, end = R.x + R.y, b = R.z;
-      float4 aq[AP4];
-#pragma unroll
-      for (int k = 0; k < AP4; ++k) aq[k] = A.a_q[(int64_t)b * AP4 + k];
-      const int2* bm_row = A.bm_old + (int64_t)b * A.W;
-      float4 acc = f4zero();
+  // ---- block-level in-order queue: slot = {b0, vr0, count} of the step's first item -------------------
+  constexpr int STEP = WPB * (DENSE ? GW : 64);
+  __shared__ int slot[2][4];
+  int q = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7;   // HW_REG_XCC_ID: speed only
+  int n_dry = 0;
+  // thread 0: take the ticket `off` of queue q (or steal); returns false when every queue is dry
+  auto resolve = [&](int off, int* out) -> bool {
+    for (;;) {
+      const int64_t qs = A.n_items * q / 8, ql = A.n_items * (q + 1) / 8 - qs;
+      if (off < ql) {
+        const int64_t item = qs + off;
+        const int b0 = (int)(item / A.n_vrows);
+        out[0] = b0; out[1] = (int)(item - (int64_t)b0 * A.n_vrows); out[2] = (int)min((int64_t)STEP, ql - off);
+        return true;
+      }
+      q = (q + 1) & 7;
+      if (++n_dry == 8) { out[2] = 0; return false; }
+      off = atomicAdd(&A.queues[q], STEP);
+    }
+  };
+  if (threadIdx.x == 0) resolve(atomicAdd(&A.queues[q], STEP), slot[0]);
+  int4* my_recs = recs + wv * 64;
+  for (int p = 0;; p ^= 1) {
+    __syncthreads();
+    const int b0 = slot[p][0], vr0 = slot[p][1], cnt_items = slot[p][2];
+    if (cnt_items == 0) break;
+    int next_off = 0;
+    if (threadIdx.x == 0) next_off = atomicAdd(&A.queues[q], STEP);     // prefetch the next ticket
 
-      for (int c0 = beg; c0 < end; c0 += G) {
-        // ---- phase 1: one candidate in-edge per lane ---------------------------------------------
-        const int c = c0 + lane_g;
-        bool valid = c < end;
-        int s = 0, r = 0;
-        float alpha = 0.f;
-        if (valid) {
-          const int2 hr = A.in_hr[c];
-          const int2 wp = bm_row[hr.x >> 5];
-          const uint32_t word = (uint32_t)wp.x, bit = hr.x & 31;
-          valid = (word >> bit) & 1u;
-          if (valid) {
-            s = wp.y + __popc(word & ((1u << bit) - 1u));
-            r = hr.y;
-            float z = b_alpha;
-#pragma unroll
-            for (int k = 0; k < AP4; ++k) {
-              const float4 as = A.a_s[(int64_t)s * AP4 + k];
-              const float4 ar = ar_l[r * AP4 + k];
-              const float4 w = w_l[k];
-              z = fmaf(w.x, fmaxf(as.x + ar.x + aq[k].x, 0.f), z);
-              z = fmaf(w.y, fmaxf(as.y + ar.y + aq[k].y, 0.f), z);
-              z = fmaf(w.z, fmaxf(as.z + ar.z + aq[k].z, 0.f), z);
-              z = fmaf(w.w, fmaxf(as.w + ar.w + aq[k].w, 0.f), z);
-            }
-            alpha = 1.0f / (1.0f + expf(-z));
-          }
-        }
-        const unsigned long long m = (__ballot(valid) >> gshift) & gmask;
-        const int cnt = __popcll(m);
-        const int pos = __popcll(m & ((1ull << lane_g) - 1ull));
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // previous round's reads are done
-        __builtin_amdgcn_wave_barrier();
-        if (lane_g >= cnt) my_stage[lane_g] = f4zero();          // pad tuples: alpha = 0, row 0
-        if (valid) my_stage[pos] = make_float4(__int_as_float(s), __int_as_float(r), alpha, 0.f);
+    if constexpr (DENSE) {
+      const int idx = wv * GW + gi_w;
+      int b = b0, vr = vr0 + idx;
+      while (vr >= A.n_vrows) { vr -= A.n_vrows; ++b; }
+      int4 R = make_int4(0, 0, 0, 0);
+      const bool live = idx < cnt_items && test_item(b, vr, R);
+      const float4 acc = run_item(live ? R.x : 0, live ? R.x + R.y : 0, R.z);
+      if (live) store_row(R.w, acc);
+    } else {
+      const int idx = wv * 64 + lane;
+      int b = b0, vr = vr0 + idx;
+      while (vr >= A.n_vrows) { vr -= A.n_vrows; ++b; }
+      int4 rec = make_int4(0, 0, 0, 0);
+      const bool ok = idx < cnt_items && test_item(b, vr, rec);
+      const unsigned long long surv = __ballot(ok);
+      const int n_surv = __popcll(surv);
+      if (n_surv > 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
-
-        // ---- phase 2: one edge per group step, 4 in flight -------------------------------------
-        for (int k = 0; k < cnt; k += 4) {
-          float4 tp[4], hv[4], rv[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) tp[u] = my_stage[k + u];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int su = __float_as_int(tp[u].x), ru = __float_as_int(tp[u].y);
-            hv[u] = row_lane ? A.hidden[(int64_t)su * A.ld4 + lane_g] : f4zero();
-            rv[u] = A.rela_in_lds ? rela_l[ru * G + lane_g]
-                                  : (row_lane ? A.rela[(int64_t)ru * A.ld4 + lane_g] : f4zero());
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const float al = tp[u].z;
-            acc.x = fmaf(al, hv[u].x + rv[u].x, acc.x);
-            acc.y = fmaf(al, hv[u].y + rv[u].y, acc.y);
-            acc.z = fmaf(al, hv[u].z + rv[u].z, acc.z);
-            acc.w = fmaf(al, hv[u].w + rv[u].w, acc.w);
-          }
+        if (ok) my_recs[__popcll(surv & ((1ull << lane) - 1ull))] = rec;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        for (int j = 0; j < n_surv; j += GW) {
+          const bool live = j + gi_w < n_surv;
+          const int4 R = live ? my_recs[j + gi_w] : make_int4(0, 0, 0, 0);
+          const float4 acc = run_item(R.x, R.x + R.y, R.z);
+          if (live) store_row(R.w, acc);
         }
       }
-      if (live && row_lane) {
-        if (R.w >= 0) A.agg[(int64_t)R.w * A.ld4 + lane_g] = acc;
-        else A.partial[(int64_t)(-R.w - 1) * A.ld4 + lane_g] = acc;
-      }
     }
+    if (threadIdx.x == 0) resolve(next_off, slot[p ^ 1]);
   }
 }
 
@@ -240,20 +277,16 @@ __global__ void combine_kernel(const int4* __restrict__ split, int n_split, int 
   agg[(int64_t)o * ld4 + c] = acc;
 }
 
-template <int G, int AP4>
-int launch(const FwdArgs& A, int B, const rg_vrows& vr, hipStream_t s) {
-  constexpr int BLOCK = 256;
-  FwdArgs a = A;
-  size_t lds = (size_t)(2 * BLOCK + A.n_rela_rows * AP4 + AP4) * sizeof(float4);
-  const size_t rela_bytes = (size_t)A.n_rela_rows * G * sizeof(float4);
-  a.rela_in_lds = (lds + rela_bytes <= 40 * 1024) ? 1 : 0;
-  if (a.rela_in_lds) lds += rela_bytes;
-  RG_CHECK(lds <= 64 * 1024, "rg_layer_fwd: attention tables need %zu B of LDS (> 64 KiB)", lds);
-  RG_HIP(hipMemsetAsync(a.queues, 0, 8 * sizeof(int32_t), s));
-  const int64_t n_batches = rg::ceil_div(A.n_items, 64);
-  int grid = (int)std::min<int64_t>(rg::ceil_div(n_batches, BLOCK / 64), 256 * 8);
-  grid = std::max(grid, 8);
-  hipLaunchKernelGGL((layer_fwd_kernel<G, AP4, BLOCK>), dim3(grid), dim3(BLOCK), lds, s, a);
+template <int G, int AP4, bool PACKED, bool DENSE, bool RELA_LDS>
+int launch3(const FwdArgs& A, size_t lds, int B, const rg_vrows& vr, hipStream_t s) {
+  constexpr int BLOCK = FWD_BLOCK;
+  auto kern = layer_fwd_kernel<G, AP4, PACKED, DENSE, RELA_LDS>;
+  if (lds > 64 * 1024) RG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int per_cu = lds <= 53 * 1024 ? 3 : (lds <= 80 * 1024 ? 2 : 1);
+  const int64_t steps = rg::ceil_div(A.n_items, (int64_t)(BLOCK / 64) * (DENSE ? 64 / G : 64));
+  const int grid = (int)std::max<int64_t>(std::min<int64_t>(steps, 256 * per_cu), 1);
+  RG_HIP(hipMemsetAsync(A.queues, 0, 8 * sizeof(int32_t), s));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds, s, A);
   RG_LAUNCH_CHECK();
   if (vr.n_split > 0) {
     const int64_t threads = (int64_t)B * vr.n_split * A.ld4;
@@ -264,14 +297,30 @@ int launch(const FwdArgs& A, int B, const rg_vrows& vr, hipStream_t s) {
   return 0;
 }
 
+template <int G, int AP4, bool PACKED, bool DENSE>
+int launch2(const FwdArgs& A, int B, const rg_vrows& vr, hipStream_t s) {
+  size_t lds = (size_t)(FWD_BLOCK + A.n_rela_rows * AP4 + AP4) * sizeof(float4);
+  if (!DENSE) lds += (size_t)FWD_BLOCK * sizeof(int4);
+  const size_t rela_bytes = (size_t)A.n_rela_rows * G * sizeof(float4);
+  RG_CHECK(lds <= 160 * 1024, "rg_layer_fwd: attention tables need %zu B of LDS (> 160 KiB)", lds);
+  if (lds + rela_bytes <= 53 * 1024) return launch3<G, AP4, PACKED, DENSE, true>(A, lds + rela_bytes, B, vr, s);   // 2 blocks per CU
+  return launch3<G, AP4, PACKED, DENSE, false>(A, lds, B, vr, s);
+}
+
+template <int G, int AP4>
+int launch(const FwdArgs& A, int B, const rg_vrows& vr, bool dense, hipStream_t s) {
+  if (A.in_pk) return dense ? launch2<G, AP4, true, true>(A, B, vr, s) : launch2<G, AP4, true, false>(A, B, vr, s);
+  return dense ? launch2<G, AP4, false, true>(A, B, vr, s) : launch2<G, AP4, false, false>(A, B, vr, s);
+}
+
 template <int G>
-int launch_ap(const FwdArgs& A, int ap4, int B, const rg_vrows& vr, hipStream_t s) {
+int launch_ap(const FwdArgs& A, int ap4, int B, const rg_vrows& vr, bool dense, hipStream_t s) {
   switch (ap4) {
-    case 1: return launch<G, 1>(A, B, vr, s);
-    case 2: return launch<G, 2>(A, B, vr, s);
-    case 3: return launch<G, 3>(A, B, vr, s);
-    case 4: return launch<G, 4>(A, B, vr, s);
-    case 8: return launch<G, 8>(A, B, vr, s);
+    case 1: return launch<G, 1>(A, B, vr, dense, s);
+    case 2: return launch<G, 2>(A, B, vr, dense, s);
+    case 3: return launch<G, 3>(A, B, vr, dense, s);
+    case 4: return launch<G, 4>(A, B, vr, dense, s);
+    case 8: return launch<G, 8>(A, B, vr, dense, s);
     default: rg::set_error("rg_layer_fwd: padded attention dim %d not in {4,8,12,16,32}", ap4 * 4); return 1;
   }
 }
@@ -302,22 +351,24 @@ extern "C" int rg_layer_fwd(const rg_frontier* f, const rg_graph* g, int32_t lev
            scratch_bytes, need);
   RG_CHECK((int64_t)f->B * std::max(g->in_vr.n_slots, 1) < ((int64_t)1 << 31), "rg_layer_fwd: batch * hub segments overflows int32");
   const int64_t n_items = (int64_t)f->B * g->in_vr.n;
-  RG_CHECK(n_items / 8 + 64 < ((int64_t)1 << 31) - ((int64_t)1 << 24), "rg_layer_fwd: work space too large for 32-bit queues");
   if (n_new == 0) return 0;
   FwdArgs A;
   A.n_items = n_items; A.n_vrows = g->in_vr.n; A.n_slots = g->in_vr.n_slots; A.vrows = g->in_vr.rows;
-  A.in_hr = g->in_hr;
+  A.in_hr = g->in_hr; A.in_pk = g->in_pk;
   A.bm_old = f->bm_of(level - 1); A.bm_new = f->bm_of(level); A.W = f->W;
   A.hidden = (const float4*)hidden; A.rela = (const float4*)rela; A.ld4 = ld / 4;
   A.a_s = (const float4*)a_s; A.a_r = (const float4*)a_r; A.a_q = (const float4*)a_q;
   A.w_alpha = w_alpha; A.b_alpha = b_alpha; A.attn_dim = attn_dim;
   A.n_rela_rows = 2 * g->n_rel + 1; A.rela_in_lds = 0;
   A.agg = (float4*)agg_out; A.partial = (float4*)scratch; A.queues = f->counters + 16;
+  RG_CHECK(n_items / 8 + ((int64_t)1 << 26) < ((int64_t)1 << 31), "rg_layer_fwd: work space too large for 32-bit queue tickets");
   hipStream_t s = (hipStream_t)stream;
+  // dense walk when at least a quarter of all (query, entity) pairs are visited; else filter 64 items per wave
+  const bool dense = n_new * 4 >= (int64_t)f->B * f->n_ent;
   const int ld4 = ld / 4;
-  if (ld4 <= 4) return launch_ap<4>(A, ap / 4, f->B, g->in_vr, s);
-  if (ld4 <= 8) return launch_ap<8>(A, ap / 4, f->B, g->in_vr, s);
-  if (ld4 <= 16) return launch_ap<16>(A, ap / 4, f->B, g->in_vr, s);
-  if (ld4 <= 32) return launch_ap<32>(A, ap / 4, f->B, g->in_vr, s);
-  return launch_ap<64>(A, ap / 4, f->B, g->in_vr, s);
+  if (ld4 <= 4) return launch_ap<4>(A, ap / 4, f->B, g->in_vr, dense, s);
+  if (ld4 <= 8) return launch_ap<8>(A, ap / 4, f->B, g->in_vr, dense, s);
+  if (ld4 <= 16) return launch_ap<16>(A, ap / 4, f->B, g->in_vr, dense, s);
+  if (ld4 <= 32) return launch_ap<32>(A, ap / 4, f->B, g->in_vr, dense, s);
+  return launch_ap<64>(A, ap / 4, f->B, g->in_vr, dense, s);
 }

@@ -279,3 +279,30 @@ def test_fused_dense_kernel_matches_torch_dense_path(d, a, act):
         np.testing.assert_allclose(x["hidden"].cpu().numpy(), y["hidden"].cpu().numpy(), rtol=RTOL, atol=ATOL_H)
     np.testing.assert_allclose(s1.cpu().numpy(), s2.cpu().numpy(), rtol=RTOL, atol=ATOL_H)
     assert torch.equal(s1 == 0, s2 == 0)
+
+
+def test_training_learns_on_family():
+    """End-to-end drop-in check on real data: the reference's loop (BaseModel.train_batch: forward, the
+    reference's loss, HIP backward, Adam, NaN scrub, filtered evaluation on the device) learns family.
+    The reference reaches MRR ~0.98 after tens of epochs; here a fraction of one epoch must already lift the
+    validation MRR far above the untrained model's."""
+    from red_gnn_amd.base_model import BaseModel
+    from red_gnn_amd.load_data import DataLoader
+    from red_gnn_amd.utils import cal_performance
+    ids = U.load("family_ids.npz")
+    loader = DataLoader(ids=ids, verbose=False)
+
+    class Opt:
+        lr, decay_rate, lamb, hidden_dim, attn_dim, n_layer, dropout, act, n_batch, n_tbatch = \
+            0.0036, 0.999, 0.000017, 48, 5, 3, 0.29, "relu", 20, 50
+        n_rel = loader.n_rel
+
+    np.random.seed(1234)
+    torch.manual_seed(1234)
+    bm = BaseModel(Opt, loader)
+    bm.model.eval()
+    mrr0, _, _ = cal_performance(bm._rank_split("valid", 500))
+    bm.n_valid, bm.n_test = 500, 200            # keep the test short: evaluate on a slice
+    mrr1, out = bm.train_batch(epoch=0, max_batches=150)
+    assert np.isfinite(bm.last_epoch_loss)
+    assert mrr1 > max(0.5, 3 * mrr0), (mrr0, mrr1, out)
