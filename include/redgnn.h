@@ -101,17 +101,19 @@ int rg_layer_fwd(const rg_frontier* f, const rg_graph* g, int32_t level, int64_t
                  float* agg_out, void* scratch_dev, size_t scratch_bytes, void* stream);
 
 /* ---- layer backward: adjoint of rg_layer_fwd (autograd of models.py:29-39) --------------------
- * nodes_old int32 [N_old,2] (level-1).  grad_agg [N_new, ld].  grad_hidden [N_old, ld] and
- * grad_a_s [N_old, ap] are WRITTEN; grad_rela [2R+1, ld], grad_a_r [2R+1, ap], grad_a_q [B, ap],
- * grad_w_alpha [attn_dim], grad_b_alpha [1] are ACCUMULATED into (caller zero-fills). */
-int rg_layer_bwd(const rg_frontier* f, const rg_graph* g, int32_t level,
-                 const int32_t* nodes_old, int64_t n_old,
+ * grad_agg [N_new, ld].  grad_hidden [N_old, ld] and grad_a_s [N_old, ap] are WRITTEN (every row);
+ * grad_rela [2R+1, ld], grad_a_r [2R+1, ap], grad_w_alpha [attn_dim], grad_b_alpha [1] are ACCUMULATED
+ * into (caller zero-fills).  grad_a_q [B, ap] is the per-query segment sum of grad_a_s and is left to
+ * the caller.  n_old is checked against the frontier.  scratch: rg_layer_bwd_scratch_bytes() bytes. */
+size_t rg_layer_bwd_scratch_bytes(const rg_frontier* f, const rg_graph* g, int32_t ld, int32_t ap);
+int rg_layer_bwd(const rg_frontier* f, const rg_graph* g, int32_t level, int64_t n_old,
                  const float* hidden, const float* rela, int32_t d, int32_t ld,
                  const float* a_s, const float* a_r, const float* a_q, int32_t ap,
                  const float* w_alpha, const float* b_alpha, int32_t attn_dim,
                  const float* grad_agg,
                  float* grad_hidden, float* grad_rela, float* grad_a_s, float* grad_a_r,
-                 float* grad_a_q, float* grad_w_alpha, float* grad_b_alpha, void* stream);
+                 float* grad_w_alpha, float* grad_b_alpha,
+                 void* scratch_dev, size_t scratch_bytes, void* stream);
 
 /* ---- dense epilogue of a layer (inference): replaces models.py:41 (W_h + act), :81 (h0 index_copy_, as a
  * gather by prev_idx), :82-84 (single-step nn.GRU; dropout = identity in eval), the next layer's

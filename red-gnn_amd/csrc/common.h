@@ -50,7 +50,7 @@ int scan_exclusive(const uint32_t* in, int32_t* out, int64_t n, bool popc, int32
 // rows[i] = {entity, first entry, length, slot}: slot = -1 for an entity kept whole, else the index of
 // this segment's partial sum inside the query's `n_slots` partial rows.
 // split[i] = {entity, first slot, number of segments, 0}.
-constexpr int RG_VROW_MAX = 128;
+constexpr int RG_VROW_MAX = 128;   // must stay <= 255 (walk.h packs the length into 8 bits)
 struct rg_vrows {
   int32_t n = 0, n_split = 0, n_slots = 0;
   int4* rows = nullptr;
@@ -70,6 +70,7 @@ struct rg_graph {
   // packed CSR-by-tail entries (rel << 20 | head), present when n_ent <= 2^20 and 2*n_rel+1 <= 2^12:
   // halves the structure bytes every query streams through its XCD's L2
   uint32_t* in_pk = nullptr;
+  uint32_t* out_pk = nullptr;   // same packing for the CSR-by-head: (rel << 20 | tail)
   rg_vrows in_vr, out_vr;
 };
 

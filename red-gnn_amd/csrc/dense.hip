@@ -131,6 +131,29 @@ __global__ __launch_bounds__(DENSE_T, 2) void dense_kernel(DenseArgs A) {
     }
     return acc;
   };
+  // three independent 16-row blocks against the same fragment, MFMAs interleaved so that no instruction
+  // waits on its predecessor's accumulator (16x16x4 f32: 32-cycle issue, 40-cycle dependent latency)
+  auto mma3 = [&](const float4* W0, int r0, const float4* W1, int r1, const float4* W2, int r2, const float (&f)[KS],
+                  f32x4& c0, f32x4& c1, f32x4& c2) {
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb) {
+      const float4 a0 = W0[sw<DP>(r0 + li, 4 * kb + hq)];
+      const float4 a1 = W1[sw<DP>(r1 + li, 4 * kb + hq)];
+      const float4 a2 = W2[sw<DP>(r2 + li, 4 * kb + hq)];
+      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, f[4 * kb + 0], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, f[4 * kb + 0], c1, 0, 0, 0);
+      c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.x, f[4 * kb + 0], c2, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, f[4 * kb + 1], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, f[4 * kb + 1], c1, 0, 0, 0);
+      c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.y, f[4 * kb + 1], c2, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, f[4 * kb + 2], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, f[4 * kb + 2], c1, 0, 0, 0);
+      c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.z, f[4 * kb + 2], c2, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, f[4 * kb + 3], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, f[4 * kb + 3], c1, 0, 0, 0);
+      c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.w, f[4 * kb + 3], c2, 0, 0, 0);
+    }
+  };
   // accumulator row of register r of block ob in this lane: 16*ob + 4*hq + r
   auto bias_acc = [&](int g, int ob) -> f32x4 {
     const float4 v = *reinterpret_cast<const float4*>(bias_l + g * DP + 16 * ob + 4 * hq);
@@ -139,27 +162,37 @@ __global__ __launch_bounds__(DENSE_T, 2) void dense_kernel(DenseArgs A) {
   };
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-  for (int t = blockIdx.x * NW + wv; t < A.n_tiles; t += gridDim.x * NW) {
+  // tile loads (agg rows: coalesced; old state: rows gathered by prev_idx), software-pipelined one tile ahead
+  constexpr int NL = 16 * S / 64;
+  auto load_tile = [&](int t, float4 (&va)[NL], float4 (&vh)[NL], bool& has_old) {
     const int64_t row0 = (int64_t)t * 16;
-    // ---- issue both tile loads (agg rows: coalesced; old state: gathered rows) ---------------------------------
-    float4 va[16 * S / 64], vh[16 * S / 64];
+    has_old = false;
 #pragma unroll
-    for (int it = 0; it < 16 * S / 64; ++it) {
+    for (int it = 0; it < NL; ++it) {
       const int e = it * 64 + lane, r = e / S, sl = e - r * S;
       va[it] = make_float4(0.f, 0.f, 0.f, 0.f);
       vh[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row0 + r < A.n && sl < A.ld4) {
+      if (t < A.n_tiles && row0 + r < A.n && sl < A.ld4) {
         va[it] = A.agg[(row0 + r) * A.ld4 + sl];
         if (A.prev_idx) {
           const int p = A.prev_idx[row0 + r];
-          if (p >= 0) vh[it] = A.hprev[(int64_t)p * A.ld4 + sl];
+          if (p >= 0) { vh[it] = A.hprev[(int64_t)p * A.ld4 + sl]; has_old = true; }
         }
       }
     }
+  };
+
+  float4 va[NL], vh[NL];
+  bool has_old = false;
+  const int t_step = gridDim.x * NW;
+  int t = blockIdx.x * NW + wv;
+  if (t < A.n_tiles) load_tile(t, va, vh, has_old);
+  for (; t < A.n_tiles; t += t_step) {
+    const int64_t row0 = (int64_t)t * 16;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int it = 0; it < 16 * S / 64; ++it) {
+    for (int it = 0; it < NL; ++it) {
       const int e = it * 64 + lane, r = e / S, sl = e - r * S;
       tile[sw<DP>(r, sl)] = va[it];
     }
@@ -170,7 +203,7 @@ __global__ __launch_bounds__(DENSE_T, 2) void dense_kernel(DenseArgs A) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int it = 0; it < 16 * S / 64; ++it) {
+    for (int it = 0; it < NL; ++it) {
       const int e = it * 64 + lane, r = e / S, sl = e - r * S;
       tile[sw<DP>(r, sl)] = vh[it];
     }
@@ -178,19 +211,40 @@ __global__ __launch_bounds__(DENSE_T, 2) void dense_kernel(DenseArgs A) {
     __builtin_amdgcn_wave_barrier();
     float hf[KS];
     read_frag(hf);
+    // a tile of new nodes only (every node of the early hops) has h = 0: its three W_hh products vanish
+    const bool any_old = __ballot(has_old) != 0ull;
+    // next tile's loads fly under this tile's MFMAs
+    load_tile(t + t_step, va, vh, has_old);
 
     // ---- stage 1: x = act(W_h agg)   (accumulators become the next B fragment) ---------------------------
     float xf[KS];
+    {
+      f32x4 acc[NB];
 #pragma unroll
-    for (int ob = 0; ob < NB; ++ob) {
-      f32x4 acc = mma(Wh_l, 16 * ob, fx, zero4);
+      for (int ob = 0; ob < NB; ++ob) acc[ob] = zero4;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float v = acc[r];
-        if (A.act == 1) v = fmaxf(v, 0.f);
-        else if (A.act == 2) v = fast_tanh(v);
-        xf[4 * ob + r] = v;
+      for (int kb = 0; kb < NB; ++kb) {
+        float4 a[NB];
+#pragma unroll
+        for (int ob = 0; ob < NB; ++ob) a[ob] = Wh_l[sw<DP>(16 * ob + li, 4 * kb + hq)];
+#pragma unroll
+        for (int ob = 0; ob < NB; ++ob) acc[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ob].x, fx[4 * kb + 0], acc[ob], 0, 0, 0);
+#pragma unroll
+        for (int ob = 0; ob < NB; ++ob) acc[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ob].y, fx[4 * kb + 1], acc[ob], 0, 0, 0);
+#pragma unroll
+        for (int ob = 0; ob < NB; ++ob) acc[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ob].z, fx[4 * kb + 2], acc[ob], 0, 0, 0);
+#pragma unroll
+        for (int ob = 0; ob < NB; ++ob) acc[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ob].w, fx[4 * kb + 3], acc[ob], 0, 0, 0);
       }
+#pragma unroll
+      for (int ob = 0; ob < NB; ++ob)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[ob][r];
+          if (A.act == 1) v = fmaxf(v, 0.f);
+          else if (A.act == 2) v = fast_tanh(v);
+          xf[4 * ob + r] = v;
+        }
     }
 
     // ---- GRU gates ([r; z; n] row blocks of weight_ih / weight_hh) -----------------------------------------
@@ -198,12 +252,8 @@ __global__ __launch_bounds__(DENSE_T, 2) void dense_kernel(DenseArgs A) {
 #pragma unroll
     for (int ob = 0; ob < NB; ++ob) {
       f32x4 ar = bias_acc(0, ob), az = bias_acc(1, ob), ai = bias_acc(2, ob), ah = bias_acc(3, ob);
-      ar = mma(Wih_l, 0 * DP + 16 * ob, xf, ar);
-      az = mma(Wih_l, 1 * DP + 16 * ob, xf, az);
-      ai = mma(Wih_l, 2 * DP + 16 * ob, xf, ai);
-      ah = mma(Whh_l, 2 * DP + 16 * ob, hf, ah);
-      ar = mma(Whh_l, 0 * DP + 16 * ob, hf, ar);
-      az = mma(Whh_l, 1 * DP + 16 * ob, hf, az);
+      mma3(Wih_l, 0 * DP + 16 * ob, Wih_l, 1 * DP + 16 * ob, Wih_l, 2 * DP + 16 * ob, xf, ar, az, ai);
+      if (any_old) mma3(Whh_l, 0 * DP + 16 * ob, Whh_l, 1 * DP + 16 * ob, Whh_l, 2 * DP + 16 * ob, hf, ar, az, ah);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float rg = fast_sigmoid(ar[r]), zg = fast_sigmoid(az[r]);

@@ -229,6 +229,9 @@ int rg_graph_create(int32_t n_ent, int32_t n_rel, const int32_t* triples, int64_
     for (int64_t i = 0; i < n_fact; ++i) pk[i] = ((uint32_t)in_hr[i].y << 20) | (uint32_t)in_hr[i].x;
     RG_HIP_G(hipMalloc(&g->in_pk, n_fact * sizeof(uint32_t)));
     RG_HIP_G(hipMemcpy(g->in_pk, pk.data(), n_fact * sizeof(uint32_t), hipMemcpyHostToDevice));
+    for (int64_t i = 0; i < n_fact; ++i) pk[i] = ((uint32_t)out_rt[i].x << 20) | (uint32_t)out_rt[i].y;
+    RG_HIP_G(hipMalloc(&g->out_pk, n_fact * sizeof(uint32_t)));
+    RG_HIP_G(hipMemcpy(g->out_pk, pk.data(), n_fact * sizeof(uint32_t), hipMemcpyHostToDevice));
   }
 #undef RG_HIP_G
   if (build_vrows(in_ptr, n_ent, &g->in_vr) || build_vrows(out_ptr, n_ent, &g->out_vr)) return fail();
@@ -243,6 +246,7 @@ int rg_graph_destroy(rg_graph* g) {
   if (g->out_rt) (void)hipFree(g->out_rt);
   if (g->in_hr) (void)hipFree(g->in_hr);
   if (g->in_pk) (void)hipFree(g->in_pk);
+  if (g->out_pk) (void)hipFree(g->out_pk);
   for (rg_vrows* v : {&g->in_vr, &g->out_vr}) {
     if (v->rows) (void)hipFree(v->rows);
     if (v->split) (void)hipFree(v->split);

@@ -1,26 +1,27 @@
 // Fused relational message passing, backward (adjoint of layer_fwd.hip).
 // Replaces what autograd replays for Static/transductive/models.py:29-39 (index / add / Linear x3 /
 // sigmoid / mul / scatter) on E-row temporaries.  Source-pull formulation: every node (b,h) of the
-// previous frontier walks its KG out-edges (CSR by head); every out-edge of a visited node is an
-// edge of the hop, its destination id is the popcount rank of (b,t) in the new frontier.
+// previous frontier walks its KG out-edges (CSR by head, cut into length-sorted virtual rows exactly as
+// the forward's CSR by tail); every out-edge of a visited node is an edge of the hop, its destination id
+// is the popcount rank of (b,t) in the new frontier.
 //
 //   per edge e=(s,r,o):   m = H[s] + Rel[r];  z = relu(a_s[s] + a_r[r] + a_q[b]);  alpha = sigma(w.z + b_alpha)
 //     g_alpha = <G[o], m>                    g_p  = g_alpha * alpha (1 - alpha)     g_z = g_p * w * 1[z>0]
-//     dH[s]   += alpha G[o]   (registers, one store per source row: deterministic)
-//     dA_s[s] += g_z          (registers -> one store per source)
-//     dRel[r] += alpha G[o]   (2R+1 rows only: privatised in LDS, flushed once per block)
+//     dH[s]   += alpha G[o]   (registers, one store per source row / segment: deterministic)
+//     dA_s[s] += g_z          (registers -> one store per source / segment)
+//     dRel[r] += alpha G[o]   (2R+1 rows only: privatised in LDS, flushed once per workgroup)
 //     dA_r[r] += g_z          (LDS)            dw += g_p relu(z), db += g_p   (registers -> block reduce)
 //   dA_q[b] = sum of dA_s over the nodes of query b is left to the caller (a segment sum).
 // The projections a_s = H Ws^T etc. are differentiated by the caller (dense GEMMs).
-#include "common.h"
+// Work distribution: walk.h (in-order per-XCD queues; grad_agg rows of the query being processed stay in L2).
+#include "walk.h"
 
 namespace {
 
 struct BwdArgs {
-  const int32_t* nodes_old;
-  int64_t n_old;
-  const int32_t* out_ptr;
+  rg::WalkArgs walk;   // items tested against the OLD frontier (sources); vrows = CSR-by-head segments
   const int2* out_rt;
+  const uint32_t* out_pk;
   const int2* bm_new;
   int W;
   const float4* hidden;
@@ -33,15 +34,15 @@ struct BwdArgs {
   const float* b_alpha;
   int attn_dim;
   int n_rela_rows;
-  int rela_in_lds;
   const float4* grad_agg;
   float4* g_hidden;
-  float* g_rela;  // [n_rela_rows][ld]
+  float4* g_hidden_part;  // [B*n_slots][ld4]
   float4* g_as;
-  float* g_ar;    // [n_rela_rows][ap]
+  float4* g_as_part;      // [B*n_slots][AP4]
+  float* g_rela;          // [n_rela_rows][ld]
+  float* g_ar;            // [n_rela_rows][ap]
   float* g_w;
   float* g_b;
-  int n_chunks;
 };
 
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -68,18 +69,21 @@ __device__ __forceinline__ float group_sum(float v) {
   return v;
 }
 
-template <int G, int AP4, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void layer_bwd_kernel(BwdArgs A) {
+constexpr int BWD_BLOCK = 512;
+
+template <int G, int AP4, bool PACKED, bool DENSE, bool RELA_LDS>
+__global__ __launch_bounds__(BWD_BLOCK, 4) void layer_bwd_kernel(BwdArgs A) {
   extern __shared__ float4 lds[];
-  constexpr int GPB = BLOCK / G;
+  constexpr int BLOCK = BWD_BLOCK;
   const int nr = A.n_rela_rows;
   float4* stage = lds;                      // [BLOCK] {o, r, alpha, g_alpha}
   float4* ar_l = stage + BLOCK;             // [nr][AP4]
   float4* w_l = ar_l + nr * AP4;            // [AP4]
   float4* gar_l = w_l + AP4;                // [nr][AP4]   grad a_r
   float4* red_l = gar_l + nr * AP4;         // [(BLOCK/64)][AP4 + 1] block reduction of dw, db
-  float4* rela_l = red_l + (BLOCK / 64) * (AP4 + 1);   // [nr][G]  (optional)
-  float4* grela_l = rela_l + nr * G;                   // [nr][G]  (optional)
+  float4* rela_l = red_l + (BLOCK / 64) * (AP4 + 1);            // [nr][G]  (RELA_LDS)
+  float4* grela_l = rela_l + (RELA_LDS ? nr * G : 0);           // [nr][G]  (RELA_LDS)
+  int4* recs = reinterpret_cast<int4*>(grela_l + (RELA_LDS ? nr * G : 0));   // [BLOCK] (SPARSE only)
 
   for (int i = threadIdx.x; i < nr * AP4; i += BLOCK) { ar_l[i] = A.a_r[i]; gar_l[i] = f4zero(); }
   if (threadIdx.x < AP4) {
@@ -90,7 +94,7 @@ __global__ __launch_bounds__(BLOCK) void layer_bwd_kernel(BwdArgs A) {
     }
     w_l[threadIdx.x] = make_float4(w[0], w[1], w[2], w[3]);
   }
-  if (A.rela_in_lds) {
+  if constexpr (RELA_LDS) {
     for (int i = threadIdx.x; i < nr * G; i += BLOCK) {
       const int r = i / G, c = i - r * G;
       rela_l[i] = c < A.ld4 ? A.rela[(int64_t)r * A.ld4 + c] : f4zero();
@@ -100,39 +104,28 @@ __global__ __launch_bounds__(BLOCK) void layer_bwd_kernel(BwdArgs A) {
   __syncthreads();
   const float b_alpha = A.b_alpha[0];
 
-  const int lane_g = threadIdx.x & (G - 1);
-  const int gi = threadIdx.x / G;
-  float4* my_stage = stage + gi * G;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lane_g = lane & (G - 1), gi_w = lane / G;
+  float4* my_stage = stage + wv * 64 + gi_w * G;
   const bool row_lane = lane_g < A.ld4;
+  const int lane_c = row_lane ? lane_g : A.ld4 - 1;
 
   float4 gw[AP4];
 #pragma unroll
   for (int k = 0; k < AP4; ++k) gw[k] = f4zero();
   float gb = 0.f;
 
-  const int x = blockIdx.x & 7, j0 = blockIdx.x >> 3, nbx = gridDim.x >> 3;
-  const int cpx = (A.n_chunks + 7) >> 3;
-  const int c_end = min((x + 1) * cpx, A.n_chunks);
-
-  for (int chunk = x * cpx + j0; chunk < c_end; chunk += nbx) {
-    const int64_t item = (int64_t)chunk * GPB + gi;
-    const bool live = item < A.n_old;
-    int b = 0, h = 0, beg = 0, end = 0;
-    if (live) {
-      b = A.nodes_old[2 * item];
-      h = A.nodes_old[2 * item + 1];
-      beg = A.out_ptr[h];
-      end = A.out_ptr[h + 1];
-    }
+  rg::walk_items<G, DENSE, BLOCK>(A.walk, recs, [&](const int4& R, bool live) {
+    const int beg = R.x, end = R.x + rg::walk_len(R), b = R.z, s_node = R.w;
     float4 base[AP4], gas[AP4];
 #pragma unroll
     for (int k = 0; k < AP4; ++k) {
-      float4 as = live ? A.a_s[item * AP4 + k] : f4zero();
-      const float4 aq = live ? A.a_q[(int64_t)b * AP4 + k] : f4zero();
+      const float4 as = A.a_s[(int64_t)s_node * AP4 + k];
+      const float4 aq = A.a_q[(int64_t)b * AP4 + k];
       base[k] = make_float4(as.x + aq.x, as.y + aq.y, as.z + aq.z, as.w + aq.w);
       gas[k] = f4zero();
     }
-    const float4 hs = (live && row_lane) ? A.hidden[item * A.ld4 + lane_g] : f4zero();
+    const float4 hs = A.hidden[(int64_t)s_node * A.ld4 + lane_c];
     const int2* bm_row = A.bm_new + (int64_t)b * A.W;
     float4 acc = f4zero();
 
@@ -147,10 +140,11 @@ __global__ __launch_bounds__(BLOCK) void layer_bwd_kernel(BwdArgs A) {
 #pragma unroll
       for (int k = 0; k < AP4; ++k) zr[k] = f4zero();
       if (valid) {
-        const int2 rt = A.out_rt[c];
-        r = rt.x;
-        const int2 wp = bm_row[rt.y >> 5];
-        o = wp.y + __popc((uint32_t)wp.x & ((1u << (rt.y & 31)) - 1u));
+        int tl;
+        if constexpr (PACKED) { const uint32_t pk = A.out_pk[c]; tl = pk & 0xFFFFF; r = pk >> 20; }
+        else { const int2 rt = A.out_rt[c]; r = rt.x; tl = rt.y; }
+        const int2 wp = bm_row[tl >> 5];
+        o = wp.y + __popc((uint32_t)wp.x & ((1u << (tl & 31)) - 1u));
         float z = b_alpha;
 #pragma unroll
         for (int k = 0; k < AP4; ++k) {
@@ -163,7 +157,7 @@ __global__ __launch_bounds__(BLOCK) void layer_bwd_kernel(BwdArgs A) {
           z = fmaf(w.z, zr[k].z, z);
           z = fmaf(w.w, zr[k].w, z);
         }
-        alpha = 1.0f / (1.0f + expf(-z));
+        alpha = __frcp_rn(1.0f + __expf(-z));
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_wave_barrier();
@@ -173,35 +167,34 @@ __global__ __launch_bounds__(BLOCK) void layer_bwd_kernel(BwdArgs A) {
 
       // ---- phase 2: one edge per group step -------------------------------------------------------
       for (int k = 0; k < cnt; k += 2) {
-        float4 tp[2], gv[2], rv[2];
+        float4 tp[2], gv[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) tp[u] = my_stage[k + u];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int ou = __float_as_int(tp[u].x), ru = __float_as_int(tp[u].y);
-          gv[u] = row_lane ? A.grad_agg[(int64_t)ou * A.ld4 + lane_g] : f4zero();
-          rv[u] = A.rela_in_lds ? rela_l[ru * G + lane_g] : (row_lane ? A.rela[(int64_t)ru * A.ld4 + lane_g] : f4zero());
-        }
+        for (int u = 0; u < 2; ++u) gv[u] = A.grad_agg[(int64_t)__float_as_int(tp[u].x) * A.ld4 + lane_c];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           const float al = tp[u].z;
           const int ru = __float_as_int(tp[u].y);
-          float dot = gv[u].x * (hs.x + rv[u].x);
-          dot = fmaf(gv[u].y, hs.y + rv[u].y, dot);
-          dot = fmaf(gv[u].z, hs.z + rv[u].z, dot);
-          dot = fmaf(gv[u].w, hs.w + rv[u].w, dot);
+          float4 rv;
+          if constexpr (RELA_LDS) rv = rela_l[ru * G + lane_g];
+          else rv = A.rela[(int64_t)ru * A.ld4 + lane_c];
+          float dot = 0.f;
+          if (row_lane) {
+            dot = gv[u].x * (hs.x + rv.x);
+            dot = fmaf(gv[u].y, hs.y + rv.y, dot);
+            dot = fmaf(gv[u].z, hs.z + rv.z, dot);
+            dot = fmaf(gv[u].w, hs.w + rv.w, dot);
+          }
           dot = group_sum<G>(dot);
           if (lane_g == 0) reinterpret_cast<float*>(&my_stage[k + u])[3] = dot;
           const float4 ag = make_float4(al * gv[u].x, al * gv[u].y, al * gv[u].z, al * gv[u].w);
           acc.x += ag.x; acc.y += ag.y; acc.z += ag.z; acc.w += ag.w;
           if (al != 0.f && row_lane) {
-            if (A.rela_in_lds) {
-              float* gr = reinterpret_cast<float*>(&grela_l[ru * G + lane_g]);
-              atomicAdd(gr + 0, ag.x); atomicAdd(gr + 1, ag.y); atomicAdd(gr + 2, ag.z); atomicAdd(gr + 3, ag.w);
-            } else {
-              float* gr = A.g_rela + ((int64_t)ru * A.ld4 + lane_g) * 4;
-              atomicAdd(gr + 0, ag.x); atomicAdd(gr + 1, ag.y); atomicAdd(gr + 2, ag.z); atomicAdd(gr + 3, ag.w);
-            }
+            float* gr;
+            if constexpr (RELA_LDS) gr = reinterpret_cast<float*>(&grela_l[ru * G + lane_g]);
+            else gr = A.g_rela + ((int64_t)ru * A.ld4 + lane_g) * 4;
+            atomicAdd(gr + 0, ag.x); atomicAdd(gr + 1, ag.y); atomicAdd(gr + 2, ag.z); atomicAdd(gr + 3, ag.w);
           }
         }
       }
@@ -231,7 +224,7 @@ __global__ __launch_bounds__(BLOCK) void layer_bwd_kernel(BwdArgs A) {
         }
       }
     }
-    // ---- per-source results -------------------------------------------------------------------------
+    // ---- per-source (or per-segment) results -------------------------------------------------------------
 #pragma unroll
     for (int k = 0; k < AP4; ++k) {
       gas[k].x = group_sum<G>(gas[k].x);
@@ -240,13 +233,16 @@ __global__ __launch_bounds__(BLOCK) void layer_bwd_kernel(BwdArgs A) {
       gas[k].w = group_sum<G>(gas[k].w);
     }
     if (live) {
-      if (row_lane) A.g_hidden[item * A.ld4 + lane_g] = acc;
+      const int out = rg::walk_out(R, A.walk.n_slots);
+      float4* hrow = out >= 0 ? A.g_hidden + (int64_t)out * A.ld4 : A.g_hidden_part + (int64_t)(-out - 1) * A.ld4;
+      float4* arow = out >= 0 ? A.g_as + (int64_t)out * AP4 : A.g_as_part + (int64_t)(-out - 1) * AP4;
+      if (row_lane) hrow[lane_g] = acc;
       if (lane_g == 0) {
 #pragma unroll
-        for (int k = 0; k < AP4; ++k) A.g_as[item * AP4 + k] = gas[k];
+        for (int k = 0; k < AP4; ++k) arow[k] = gas[k];
       }
     }
-  }
+  });
 
   // ---- block-level flushes ------------------------------------------------------------------------------
   __syncthreads();
@@ -254,15 +250,14 @@ __global__ __launch_bounds__(BLOCK) void layer_bwd_kernel(BwdArgs A) {
     const float v = reinterpret_cast<float*>(gar_l)[i];
     if (v != 0.f) atomicAdd(A.g_ar + i, v);
   }
-  if (A.rela_in_lds) {
+  if constexpr (RELA_LDS) {
     for (int i = threadIdx.x; i < nr * A.ld4 * 4; i += BLOCK) {
       const int r = i / (A.ld4 * 4), c = i - r * (A.ld4 * 4);
       const float v = reinterpret_cast<float*>(grela_l)[r * G * 4 + c];
       if (v != 0.f) atomicAdd(A.g_rela + i, v);
     }
   }
-  // dw, db: wave reduce -> LDS -> thread 0
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // dw, db: wave reduce -> LDS -> first threads
   float vals[AP4 * 4 + 1];
 #pragma unroll
   for (int k = 0; k < AP4; ++k) { vals[4 * k] = gw[k].x; vals[4 * k + 1] = gw[k].y; vals[4 * k + 2] = gw[k].z; vals[4 * k + 3] = gw[k].w; }
@@ -283,50 +278,94 @@ __global__ __launch_bounds__(BLOCK) void layer_bwd_kernel(BwdArgs A) {
   }
 }
 
-template <int G, int AP4>
-int launch(const BwdArgs& A, hipStream_t s) {
-  constexpr int BLOCK = 512;
-  constexpr int GPB = BLOCK / G;
-  BwdArgs a = A;
-  a.n_chunks = (int)rg::ceil_div(A.n_old, GPB);
-  size_t lds = (size_t)(BLOCK + 2 * A.n_rela_rows * AP4 + AP4 + (BLOCK / 64) * (AP4 + 1)) * sizeof(float4);
-  const size_t rela_bytes = 2 * (size_t)A.n_rela_rows * G * sizeof(float4);
-  a.rela_in_lds = (lds + rela_bytes <= 80 * 1024) ? 1 : 0;
-  if (a.rela_in_lds) lds += rela_bytes;
-  RG_CHECK(lds <= 160 * 1024, "rg_layer_bwd: attention tables need %zu B of LDS", lds);
-  if (lds > 64 * 1024)
-    RG_HIP(hipFuncSetAttribute((const void*)layer_bwd_kernel<G, AP4, BLOCK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  int grid = (int)std::min<int64_t>(a.n_chunks, 256 * 2);
-  grid = (grid + 7) & ~7;
-  hipLaunchKernelGGL((layer_bwd_kernel<G, AP4, BLOCK>), dim3(grid), dim3(BLOCK), lds, s, a);
+// hub sources cut into segments: dH[s], dA_s[s] = sums of the segments' partial rows, in segment order
+__global__ void bwd_combine_kernel(const int4* __restrict__ split, int n_split, int n_slots, int B, const int2* __restrict__ bm_old,
+                                   int W, const float4* __restrict__ hpart, const float4* __restrict__ apart,
+                                   float4* __restrict__ g_hidden, float4* __restrict__ g_as, int ld4, int ap4) {
+  const int cols = ld4 + ap4;
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t item = tid / cols;
+  const int c = (int)(tid - item * cols);
+  if (item >= (int64_t)B * n_split) return;
+  const int b = (int)(item / n_split);
+  const int4 se = split[item - (int64_t)b * n_split];
+  const int2 wp = bm_old[(int64_t)b * W + (se.x >> 5)];
+  const uint32_t word = (uint32_t)wp.x, bit = se.x & 31;
+  if (!((word >> bit) & 1u)) return;
+  const int s = wp.y + __popc(word & ((1u << bit) - 1u));
+  const bool is_h = c < ld4;
+  const int stride = is_h ? ld4 : ap4;
+  const float4* p = (is_h ? hpart : apart) + ((int64_t)b * n_slots + se.y) * stride + (is_h ? c : c - ld4);
+  float4 acc = p[0];
+  for (int k = 1; k < se.z; ++k) {
+    const float4 v = p[(int64_t)k * stride];
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  if (is_h) g_hidden[(int64_t)s * ld4 + c] = acc;
+  else g_as[(int64_t)s * ap4 + (c - ld4)] = acc;
+}
+
+template <int G, int AP4, bool PACKED, bool DENSE, bool RELA_LDS>
+int launch3(const BwdArgs& A, size_t lds, int B, const rg_vrows& vr, const int2* bm_old, hipStream_t s) {
+  auto kern = layer_bwd_kernel<G, AP4, PACKED, DENSE, RELA_LDS>;
+  if (lds > 64 * 1024) RG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int per_cu = lds <= 80 * 1024 ? 2 : 1;
+  const int grid = rg::walk_grid(A.walk.n_items, BWD_BLOCK, G, DENSE, per_cu);
+  RG_HIP(hipMemsetAsync(A.walk.queues, 0, 8 * sizeof(int32_t), s));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(BWD_BLOCK), lds, s, A);
   RG_LAUNCH_CHECK();
+  if (vr.n_split > 0) {
+    const int64_t threads = (int64_t)B * vr.n_split * (A.ld4 + AP4);
+    hipLaunchKernelGGL(bwd_combine_kernel, dim3(rg::ceil_div(threads, 256)), dim3(256), 0, s, vr.split, vr.n_split, vr.n_slots, B,
+                       bm_old, A.W, A.g_hidden_part, A.g_as_part, A.g_hidden, A.g_as, A.ld4, AP4);
+    RG_LAUNCH_CHECK();
+  }
   return 0;
 }
 
+template <int G, int AP4, bool PACKED, bool DENSE>
+int launch2(const BwdArgs& A, int B, const rg_vrows& vr, const int2* bm_old, hipStream_t s) {
+  size_t lds = (size_t)(BWD_BLOCK + 2 * A.n_rela_rows * AP4 + AP4 + (BWD_BLOCK / 64) * (AP4 + 1)) * sizeof(float4);
+  if (!DENSE) lds += (size_t)BWD_BLOCK * sizeof(int4);
+  const size_t rela_bytes = 2 * (size_t)A.n_rela_rows * G * sizeof(float4);
+  RG_CHECK(lds <= 160 * 1024, "rg_layer_bwd: attention tables need %zu B of LDS (> 160 KiB)", lds);
+  if (lds + rela_bytes <= 80 * 1024) return launch3<G, AP4, PACKED, DENSE, true>(A, lds + rela_bytes, B, vr, bm_old, s);
+  return launch3<G, AP4, PACKED, DENSE, false>(A, lds, B, vr, bm_old, s);
+}
+
+template <int G, int AP4>
+int launch(const BwdArgs& A, int B, const rg_vrows& vr, const int2* bm_old, bool dense, hipStream_t s) {
+  if (A.out_pk) return dense ? launch2<G, AP4, true, true>(A, B, vr, bm_old, s) : launch2<G, AP4, true, false>(A, B, vr, bm_old, s);
+  return dense ? launch2<G, AP4, false, true>(A, B, vr, bm_old, s) : launch2<G, AP4, false, false>(A, B, vr, bm_old, s);
+}
+
 template <int G>
-int launch_ap(const BwdArgs& A, int ap4, hipStream_t s) {
+int launch_ap(const BwdArgs& A, int ap4, int B, const rg_vrows& vr, const int2* bm_old, bool dense, hipStream_t s) {
   switch (ap4) {
-    case 1: return launch<G, 1>(A, s);
-    case 2: return launch<G, 2>(A, s);
-    case 3: return launch<G, 3>(A, s);
-    case 4: return launch<G, 4>(A, s);
-    case 8: return launch<G, 8>(A, s);
+    case 1: return launch<G, 1>(A, B, vr, bm_old, dense, s);
+    case 2: return launch<G, 2>(A, B, vr, bm_old, dense, s);
+    case 3: return launch<G, 3>(A, B, vr, bm_old, dense, s);
+    case 4: return launch<G, 4>(A, B, vr, bm_old, dense, s);
+    case 8: return launch<G, 8>(A, B, vr, bm_old, dense, s);
     default: rg::set_error("rg_layer_bwd: padded attention dim %d not in {4,8,12,16,32}", ap4 * 4); return 1;
   }
 }
 
 }  // namespace
 
-extern "C" int rg_layer_bwd(const rg_frontier* f, const rg_graph* g, int32_t level, const int32_t* nodes_old,
-                            int64_t n_old, const float* hidden, const float* rela, int32_t d, int32_t ld,
-                            const float* a_s, const float* a_r, const float* a_q, int32_t ap, const float* w_alpha,
-                            const float* b_alpha, int32_t attn_dim, const float* grad_agg, float* grad_hidden,
-                            float* grad_rela, float* grad_a_s, float* grad_a_r, float* grad_a_q, float* grad_w_alpha,
-                            float* grad_b_alpha, void* stream) {
-  RG_CHECK(f && g && nodes_old && hidden && rela && a_s && a_r && a_q && w_alpha && b_alpha && grad_agg && grad_hidden &&
-               grad_rela && grad_a_s && grad_a_r && grad_w_alpha && grad_b_alpha,
-           "rg_layer_bwd: NULL argument");
-  (void)grad_a_q;  // dA_q[b] = segment sum of dA_s over the nodes of query b: done by the caller
+extern "C" size_t rg_layer_bwd_scratch_bytes(const rg_frontier* f, const rg_graph* g, int32_t ld, int32_t ap) {
+  if (!f || !g) return 0;
+  return (size_t)f->B * g->out_vr.n_slots * (ld + ap) * sizeof(float) + 512;
+}
+
+extern "C" int rg_layer_bwd(const rg_frontier* f, const rg_graph* g, int32_t level, int64_t n_old, const float* hidden,
+                            const float* rela, int32_t d, int32_t ld, const float* a_s, const float* a_r,
+                            const float* a_q, int32_t ap, const float* w_alpha, const float* b_alpha, int32_t attn_dim,
+                            const float* grad_agg, float* grad_hidden, float* grad_rela, float* grad_a_s,
+                            float* grad_a_r, float* grad_w_alpha, float* grad_b_alpha, void* scratch,
+                            size_t scratch_bytes, void* stream) {
+  RG_CHECK(f && g && hidden && rela && a_s && a_r && a_q && w_alpha && b_alpha && grad_agg && grad_hidden && grad_rela &&
+               grad_a_s && grad_a_r && grad_w_alpha && grad_b_alpha, "rg_layer_bwd: NULL argument");
   RG_CHECK(g->n_ent == f->n_ent, "rg_layer_bwd: graph has %d entities, frontier %d", g->n_ent, f->n_ent);
   RG_CHECK(level >= 1 && level <= f->level && level > f->level - f->n_levels + 1,
            "rg_layer_bwd: level %d not resident (current %d, %d kept)", level, f->level, f->n_levels);
@@ -334,22 +373,34 @@ extern "C" int rg_layer_bwd(const rg_frontier* f, const rg_graph* g, int32_t lev
            (long long)n_old, level - 1, (long long)f->n_nodes[(level - 1) % f->n_levels]);
   RG_CHECK(d > 0 && ld >= d && ld % 4 == 0 && ld >= 16 && ld <= 256, "rg_layer_bwd: d=%d ld=%d", d, ld);
   RG_CHECK(attn_dim > 0 && ap >= attn_dim && ap % 4 == 0, "rg_layer_bwd: attn_dim=%d ap=%d", attn_dim, ap);
+  const size_t need = rg_layer_bwd_scratch_bytes(f, g, ld, ap);
+  RG_CHECK(g->out_vr.n_slots == 0 || (scratch && scratch_bytes >= need), "rg_layer_bwd: scratch %zu B < required %zu B",
+           scratch_bytes, need);
+  RG_CHECK((int64_t)f->B * std::max(g->out_vr.n_slots, 1) < ((int64_t)1 << 31) && g->out_vr.n_slots < (1 << 22),
+           "rg_layer_bwd: batch * hub segments overflows int32");
+  const int64_t n_items = (int64_t)f->B * g->out_vr.n;
+  RG_CHECK(n_items / 8 + ((int64_t)1 << 26) < ((int64_t)1 << 31), "rg_layer_bwd: work space too large for 32-bit queue tickets");
   if (n_old == 0) return 0;
   BwdArgs A;
-  A.nodes_old = nodes_old; A.n_old = n_old;
-  A.out_ptr = g->out_ptr; A.out_rt = g->out_rt;
+  A.walk.n_items = n_items; A.walk.n_vrows = g->out_vr.n; A.walk.n_slots = g->out_vr.n_slots; A.walk.vrows = g->out_vr.rows;
+  A.walk.bm_test = f->bm_of(level - 1); A.walk.W = f->W; A.walk.queues = f->counters + 16;
+  A.out_rt = g->out_rt; A.out_pk = g->out_pk;
   A.bm_new = f->bm_of(level); A.W = f->W;
   A.hidden = (const float4*)hidden; A.rela = (const float4*)rela; A.ld4 = ld / 4;
   A.a_s = (const float4*)a_s; A.a_r = (const float4*)a_r; A.a_q = (const float4*)a_q;
   A.w_alpha = w_alpha; A.b_alpha = b_alpha; A.attn_dim = attn_dim;
-  A.n_rela_rows = 2 * g->n_rel + 1; A.rela_in_lds = 0;
+  A.n_rela_rows = 2 * g->n_rel + 1;
   A.grad_agg = (const float4*)grad_agg; A.g_hidden = (float4*)grad_hidden; A.g_rela = grad_rela;
-  A.g_as = (float4*)grad_a_s; A.g_ar = grad_a_r; A.g_w = grad_w_alpha; A.g_b = grad_b_alpha; A.n_chunks = 0;
+  A.g_as = (float4*)grad_a_s; A.g_ar = grad_a_r; A.g_w = grad_w_alpha; A.g_b = grad_b_alpha;
+  A.g_hidden_part = (float4*)scratch;
+  A.g_as_part = (float4*)((char*)scratch + rg::align_up((size_t)f->B * g->out_vr.n_slots * ld * sizeof(float), 256));
   hipStream_t s = (hipStream_t)stream;
+  const bool dense = n_old * 4 >= (int64_t)f->B * f->n_ent;
   const int ld4 = ld / 4;
-  if (ld4 <= 4) return launch_ap<4>(A, ap / 4, s);
-  if (ld4 <= 8) return launch_ap<8>(A, ap / 4, s);
-  if (ld4 <= 16) return launch_ap<16>(A, ap / 4, s);
-  if (ld4 <= 32) return launch_ap<32>(A, ap / 4, s);
-  return launch_ap<64>(A, ap / 4, s);
+  const int2* bm_old = f->bm_of(level - 1);
+  if (ld4 <= 4) return launch_ap<4>(A, ap / 4, f->B, g->out_vr, bm_old, dense, s);
+  if (ld4 <= 8) return launch_ap<8>(A, ap / 4, f->B, g->out_vr, bm_old, dense, s);
+  if (ld4 <= 16) return launch_ap<16>(A, ap / 4, f->B, g->out_vr, bm_old, dense, s);
+  if (ld4 <= 32) return launch_ap<32>(A, ap / 4, f->B, g->out_vr, bm_old, dense, s);
+  return launch_ap<64>(A, ap / 4, f->B, g->out_vr, bm_old, dense, s);
 }

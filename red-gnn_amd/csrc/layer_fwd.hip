@@ -29,15 +29,12 @@
 //     workgroup that finds its queue dry steals from the others, every item is processed once under
 //     any placement.
 // rela / a_r / w_alpha live in LDS.  Sums run in CSR order: bitwise reproducible.
-#include "common.h"
+#include "walk.h"
 
 namespace {
 
 struct FwdArgs {
-  int64_t n_items;   // B * n_vrows
-  int32_t n_vrows;
-  int32_t n_slots;
-  const int4* vrows;
+  rg::WalkArgs walk;   // items tested against the NEW frontier (destinations)
   const int2* in_hr;
   const uint32_t* in_pk;
   const int2* bm_old;
@@ -56,7 +53,6 @@ struct FwdArgs {
   int rela_in_lds;
   float4* agg;
   float4* partial;
-  int32_t* queues;  // [8] item offsets inside each eighth, zeroed before the launch
 };
 
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -181,78 +177,10 @@ __global__ __launch_bounds__(FWD_BLOCK, 6) void layer_fwd_kernel(FwdArgs A) {
     if (out >= 0) A.agg[(int64_t)out * A.ld4 + lane_g] = acc;
     else A.partial[(int64_t)(-out - 1) * A.ld4 + lane_g] = acc;
   };
-  // (b, vrow) -> {beg, len, b, out} if (b, entity) is in the new frontier
-  auto test_item = [&](int b, int vr, int4& rec) -> bool {
-    const int4 row = A.vrows[vr];
-    const int2 wp = A.bm_new[(int64_t)b * A.W + (row.x >> 5)];
-    const uint32_t word = (uint32_t)wp.x, bit = row.x & 31;
-    if (!((word >> bit) & 1u)) return false;
-    const int o = wp.y + __popc(word & ((1u << bit) - 1u));
-    rec = make_int4(row.y, row.z, b, row.w < 0 ? o : -(b * A.n_slots + row.w) - 1);
-    return true;
-  };
-
-  // ---- block-level in-order queue: slot = {b0, vr0, count} of the step's first item -------------------
-  constexpr int STEP = WPB * (DENSE ? GW : 64);
-  __shared__ int slot[2][4];
-  int q = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7;   // HW_REG_XCC_ID: speed only
-  int n_dry = 0;
-  // thread 0: take the ticket `off` of queue q (or steal); returns false when every queue is dry
-  auto resolve = [&](int off, int* out) -> bool {
-    for (;;) {
-      const int64_t qs = A.n_items * q / 8, ql = A.n_items * (q + 1) / 8 - qs;
-      if (off < ql) {
-        const int64_t item = qs + off;
-        const int b0 = (int)(item / A.n_vrows);
-        out[0] = b0; out[1] = (int)(item - (int64_t)b0 * A.n_vrows); out[2] = (int)min((int64_t)STEP, ql - off);
-        return true;
-      }
-      q = (q + 1) & 7;
-      if (++n_dry == 8) { out[2] = 0; return false; }
-      off = atomicAdd(&A.queues[q], STEP);
-    }
-  };
-  if (threadIdx.x == 0) resolve(atomicAdd(&A.queues[q], STEP), slot[0]);
-  int4* my_recs = recs + wv * 64;
-  for (int p = 0;; p ^= 1) {
-    __syncthreads();
-    const int b0 = slot[p][0], vr0 = slot[p][1], cnt_items = slot[p][2];
-    if (cnt_items == 0) break;
-    int next_off = 0;
-    if (threadIdx.x == 0) next_off = atomicAdd(&A.queues[q], STEP);     // prefetch the next ticket
-
-    if constexpr (DENSE) {
-      const int idx = wv * GW + gi_w;
-      int b = b0, vr = vr0 + idx;
-      while (vr >= A.n_vrows) { vr -= A.n_vrows; ++b; }
-      int4 R = make_int4(0, 0, 0, 0);
-      const bool live = idx < cnt_items && test_item(b, vr, R);
-      const float4 acc = run_item(live ? R.x : 0, live ? R.x + R.y : 0, R.z);
-      if (live) store_row(R.w, acc);
-    } else {
-      const int idx = wv * 64 + lane;
-      int b = b0, vr = vr0 + idx;
-      while (vr >= A.n_vrows) { vr -= A.n_vrows; ++b; }
-      int4 rec = make_int4(0, 0, 0, 0);
-      const bool ok = idx < cnt_items && test_item(b, vr, rec);
-      const unsigned long long surv = __ballot(ok);
-      const int n_surv = __popcll(surv);
-      if (n_surv > 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        if (ok) my_recs[__popcll(surv & ((1ull << lane) - 1ull))] = rec;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        for (int j = 0; j < n_surv; j += GW) {
-          const bool live = j + gi_w < n_surv;
-          const int4 R = live ? my_recs[j + gi_w] : make_int4(0, 0, 0, 0);
-          const float4 acc = run_item(R.x, R.x + R.y, R.z);
-          if (live) store_row(R.w, acc);
-        }
-      }
-    }
-    if (threadIdx.x == 0) resolve(next_off, slot[p ^ 1]);
-  }
+  rg::walk_items<G, DENSE, BLOCK>(A.walk, recs, [&](const int4& R, bool live) {
+    const float4 acc = run_item(R.x, R.x + rg::walk_len(R), R.z);
+    if (live) store_row(rg::walk_out(R, A.walk.n_slots), acc);
+  });
 }
 
 // hubs cut into segments: agg[o] = sum of the segments' partial rows, in segment order
@@ -283,9 +211,8 @@ int launch3(const FwdArgs& A, size_t lds, int B, const rg_vrows& vr, hipStream_t
   auto kern = layer_fwd_kernel<G, AP4, PACKED, DENSE, RELA_LDS>;
   if (lds > 64 * 1024) RG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int per_cu = lds <= 53 * 1024 ? 3 : (lds <= 80 * 1024 ? 2 : 1);
-  const int64_t steps = rg::ceil_div(A.n_items, (int64_t)(BLOCK / 64) * (DENSE ? 64 / G : 64));
-  const int grid = (int)std::max<int64_t>(std::min<int64_t>(steps, 256 * per_cu), 1);
-  RG_HIP(hipMemsetAsync(A.queues, 0, 8 * sizeof(int32_t), s));
+  const int grid = rg::walk_grid(A.walk.n_items, BLOCK, G, DENSE, per_cu);
+  RG_HIP(hipMemsetAsync(A.walk.queues, 0, 8 * sizeof(int32_t), s));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds, s, A);
   RG_LAUNCH_CHECK();
   if (vr.n_split > 0) {
@@ -349,18 +276,20 @@ extern "C" int rg_layer_fwd(const rg_frontier* f, const rg_graph* g, int32_t lev
   const size_t need = rg_layer_fwd_scratch_bytes(f, g, ld);
   RG_CHECK(g->in_vr.n_slots == 0 || (scratch && scratch_bytes >= need), "rg_layer_fwd: scratch %zu B < required %zu B",
            scratch_bytes, need);
-  RG_CHECK((int64_t)f->B * std::max(g->in_vr.n_slots, 1) < ((int64_t)1 << 31), "rg_layer_fwd: batch * hub segments overflows int32");
+  RG_CHECK((int64_t)f->B * std::max(g->in_vr.n_slots, 1) < ((int64_t)1 << 31) && g->in_vr.n_slots < (1 << 22),
+           "rg_layer_fwd: batch * hub segments overflows int32");
   const int64_t n_items = (int64_t)f->B * g->in_vr.n;
   if (n_new == 0) return 0;
   FwdArgs A;
-  A.n_items = n_items; A.n_vrows = g->in_vr.n; A.n_slots = g->in_vr.n_slots; A.vrows = g->in_vr.rows;
+  A.walk.n_items = n_items; A.walk.n_vrows = g->in_vr.n; A.walk.n_slots = g->in_vr.n_slots; A.walk.vrows = g->in_vr.rows;
+  A.walk.bm_test = f->bm_of(level); A.walk.W = f->W; A.walk.queues = f->counters + 16;
   A.in_hr = g->in_hr; A.in_pk = g->in_pk;
   A.bm_old = f->bm_of(level - 1); A.bm_new = f->bm_of(level); A.W = f->W;
   A.hidden = (const float4*)hidden; A.rela = (const float4*)rela; A.ld4 = ld / 4;
   A.a_s = (const float4*)a_s; A.a_r = (const float4*)a_r; A.a_q = (const float4*)a_q;
   A.w_alpha = w_alpha; A.b_alpha = b_alpha; A.attn_dim = attn_dim;
   A.n_rela_rows = 2 * g->n_rel + 1; A.rela_in_lds = 0;
-  A.agg = (float4*)agg_out; A.partial = (float4*)scratch; A.queues = f->counters + 16;
+  A.agg = (float4*)agg_out; A.partial = (float4*)scratch;
   RG_CHECK(n_items / 8 + ((int64_t)1 << 26) < ((int64_t)1 << 31), "rg_layer_fwd: work space too large for 32-bit queue tickets");
   hipStream_t s = (hipStream_t)stream;
   // dense walk when at least a quarter of all (query, entity) pairs are visited; else filter 64 items per wave

@@ -1,0 +1,119 @@
+// Work distribution shared by the layer forward and backward kernels.
+//
+// The work space is (query b, virtual row vr) in query-major order; an item is live when (b, entity of vr) is
+// in the frontier given by `bm_test`, and then carries R = {first CSR entry, length | (slot+1) << 8, b, node id}:
+// node id = popcount rank of (b, entity); slot+1 = 0 for an entity kept whole, else 1 + the index of this
+// segment's partial row inside the query's n_slots partial rows (walk_len / walk_part decode it).
+//
+// XCD x (HW_REG_XCC_ID) serves the x-th eighth of the work space from its own in-order queue, one block step
+// at a time: a workgroup takes STEP consecutive items (DENSE: one per lane group; SPARSE: 64 per wave, one lane
+// tests one item and survivors are compacted through LDS), the next ticket is prefetched while the step runs.
+// An XCD's resident workgroups therefore span a few thousand consecutive items - a fraction of ONE query -
+// so the per-query rows they gather from stay in that XCD's 4 MiB L2.  Queues only steer speed: a workgroup
+// that finds its queue dry steals from the others; every item is processed exactly once under any placement.
+#pragma once
+#include "common.h"
+
+namespace rg {
+
+struct WalkArgs {
+  int64_t n_items;   // B * n_vrows
+  int32_t n_vrows;
+  int32_t n_slots;
+  const int4* vrows;
+  const int2* bm_test;
+  int W;
+  int32_t* queues;   // [8] item offsets inside each eighth, zeroed before the launch
+};
+
+__device__ __forceinline__ int walk_len(const int4& R) { return R.y & 255; }
+// row index of the item's result: >= 0 node id (whole entity), < 0: -(partial row) - 1
+__device__ __forceinline__ int walk_out(const int4& R, int n_slots) {
+  const int sp1 = R.y >> 8;
+  return sp1 == 0 ? R.w : -(R.z * n_slots + sp1 - 1) - 1;
+}
+
+// run_item(const int4& R, bool live) is called by all 64 lanes of a wave with one item per group of G lanes.
+template <int G, bool DENSE, int BLOCK, typename F>
+__device__ __forceinline__ void walk_items(const WalkArgs& A, int4* recs, F&& run_item) {
+  constexpr int GW = 64 / G, WPB = BLOCK / 64;
+  constexpr int STEP = WPB * (DENSE ? GW : 64);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, gi_w = lane / G;
+
+  auto test_item = [&](int b, int vr, int4& rec) -> bool {
+    const int4 row = A.vrows[vr];
+    const int2 wp = A.bm_test[(int64_t)b * A.W + (row.x >> 5)];
+    const uint32_t word = (uint32_t)wp.x, bit = row.x & 31;
+    if (!((word >> bit) & 1u)) return false;
+    const int o = wp.y + __popc(word & ((1u << bit) - 1u));
+    rec = make_int4(row.y, row.z | ((row.w + 1) << 8), b, o);
+    return true;
+  };
+
+  __shared__ int slot[2][4];   // {b0, vr0, count} of the step's first item
+  int q = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7;   // HW_REG_XCC_ID: speed only
+  int n_dry = 0;
+  // thread 0: turn ticket `off` of queue q into a slot (or steal); count 0 = every queue is dry
+  auto resolve = [&](int off, int* out) {
+    for (;;) {
+      const int64_t qs = A.n_items * q / 8, ql = A.n_items * (q + 1) / 8 - qs;
+      if (off < ql) {
+        const int64_t item = qs + off;
+        const int b0 = (int)(item / A.n_vrows);
+        out[0] = b0; out[1] = (int)(item - (int64_t)b0 * A.n_vrows); out[2] = (int)min((int64_t)STEP, ql - off);
+        return;
+      }
+      q = (q + 1) & 7;
+      if (++n_dry == 8) { out[2] = 0; return; }
+      off = atomicAdd(&A.queues[q], STEP);
+    }
+  };
+  if (threadIdx.x == 0) resolve(atomicAdd(&A.queues[q], STEP), slot[0]);
+  int4* my_recs = recs + wv * 64;
+  for (int p = 0;; p ^= 1) {
+    __syncthreads();
+    const int b0 = slot[p][0], vr0 = slot[p][1], cnt_items = slot[p][2];
+    if (cnt_items == 0) break;
+    int next_off = 0;
+    if (threadIdx.x == 0) next_off = atomicAdd(&A.queues[q], STEP);     // prefetch the next ticket
+
+    if constexpr (DENSE) {
+      const int idx = wv * GW + gi_w;
+      int b = b0, vr = vr0 + idx;
+      while (vr >= A.n_vrows) { vr -= A.n_vrows; ++b; }
+      int4 R = make_int4(0, 0, 0, 0);
+      const bool live = idx < cnt_items && test_item(b, vr, R);
+      if (!live) { R.x = 0; R.y = 0; }
+      run_item(R, live);
+    } else {
+      const int idx = wv * 64 + lane;
+      int b = b0, vr = vr0 + idx;
+      while (vr >= A.n_vrows) { vr -= A.n_vrows; ++b; }
+      int4 rec = make_int4(0, 0, 0, 0);
+      const bool ok = idx < cnt_items && test_item(b, vr, rec);
+      const unsigned long long surv = __ballot(ok);
+      const int n_surv = __popcll(surv);
+      if (n_surv > 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        if (ok) my_recs[__popcll(surv & ((1ull << lane) - 1ull))] = rec;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        for (int j = 0; j < n_surv; j += GW) {
+          const bool live = j + gi_w < n_surv;
+          const int4 R = live ? my_recs[j + gi_w] : make_int4(0, 0, 0, 0);
+          run_item(R, live);
+        }
+      }
+    }
+    if (threadIdx.x == 0) resolve(next_off, slot[p ^ 1]);
+  }
+}
+
+// grid and queue reset for a walk launch
+static inline int walk_grid(int64_t n_items, int block, int g, bool dense, int per_cu) {
+  const int64_t steps = ceil_div(n_items, (int64_t)(block / 64) * (dense ? 64 / g : 64));
+  return (int)std::max<int64_t>(std::min<int64_t>(steps, 256 * per_cu), 1);
+}
+
+}  // namespace rg

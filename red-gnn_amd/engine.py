@@ -187,11 +187,14 @@ def layer_bwd(frontier, graph, level, nodes_old, hidden, rela, d, a_s, a_r, a_q,
     g_aq = torch.zeros_like(a_q)
     g_w = torch.zeros(attn_dim, dtype=torch.float32, device=dev)
     g_b = torch.zeros(1, dtype=torch.float32, device=dev)
-    _lib.check(_lib.lib().rg_layer_bwd(frontier.handle, graph.handle, level, _lib.ptr(nodes_old), n_old,
+    nbytes = _lib.lib().rg_layer_bwd_scratch_bytes(frontier.handle, graph.handle, ld, ap)
+    scratch = frontier.scratch(nbytes)
+    _lib.check(_lib.lib().rg_layer_bwd(frontier.handle, graph.handle, level, n_old,
                                        _lib.ptr(hidden), _lib.ptr(rela), d, ld, _lib.ptr(a_s), _lib.ptr(a_r),
                                        _lib.ptr(a_q), ap, _lib.ptr(w_alpha), _lib.ptr(b_alpha), attn_dim,
                                        _lib.ptr(grad_agg), _lib.ptr(g_h), _lib.ptr(g_rela), _lib.ptr(g_as),
-                                       _lib.ptr(g_ar), _lib.ptr(g_aq), _lib.ptr(g_w), _lib.ptr(g_b), _lib.stream_ptr()))
+                                       _lib.ptr(g_ar), _lib.ptr(g_w), _lib.ptr(g_b), _lib.ptr(scratch), nbytes,
+                                       _lib.stream_ptr()))
     return g_h, g_rela, g_as, g_ar, g_aq, g_w, g_b
 
 
