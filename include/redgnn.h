@@ -42,6 +42,12 @@ int rg_version(void);
  * inside every CSR row so sums are reproducible. */
 int rg_graph_create(int32_t n_ent, int32_t n_rel, const int32_t* triples_host, int64_t n,
                     int add_inverse, rg_graph** out);
+/* temporal graph (T-RED-GNN interpolation): replaces the per-call coo_matrix build of
+ * Temporal/interpolation/model_cuda.py:121-126 over the quadruple array of graph.py:34-49.
+ * quads: HOST int32 [n,4] = (head, rel, tail, time id), used as given (the reference's graph array already
+ * holds the identity rows with the sentinel timestamp); n_rela_rows = rows of the relation tables. */
+int rg_tgraph_create(int32_t n_ent, int32_t n_rela_rows, int32_t n_time, const int32_t* quads_host, int64_t n,
+                     rg_graph** out);
 int rg_graph_destroy(rg_graph* g);
 int64_t rg_graph_n_fact(const rg_graph* g);      /* rows incl. inverse + identity (load_data.py:80) */
 /* copy the device CSR back (tests): ptr arrays have n_ent+1 entries, pair arrays 2*n_fact. */
@@ -99,6 +105,19 @@ int rg_layer_fwd(const rg_frontier* f, const rg_graph* g, int32_t level, int64_t
                  const float* a_s, const float* a_r, const float* a_q, int32_t ap,
                  const float* w_alpha, const float* b_alpha, int32_t attn_dim,
                  float* agg_out, void* scratch_dev, size_t scratch_bytes, void* stream);
+
+/* ---- temporal layer forward: replaces Temporal/interpolation/model_cuda.py:149-160,192 ------------------
+ * agg[o] = sum_e alpha_e * (hidden_dir[3 s + dir_e] + rela_dir[dir_e * n_rela_rows + r] + time_dir[dir_e * n_time + |dt_e|]),
+ * dt_e = time(e) - q_time[b], dir = 0 (dt<0, past) / 1 (dt=0, now) / 2 (dt>0, future): the three direction
+ * linears applied per node / relation / |dt| by the caller (W(h+r+tau) = Wh + Wr + Wtau);
+ * alpha_e as in rg_layer_fwd with a_s, a_r, a_q the three blocks of attention_1 (no biases: pass b_alpha = 0).
+ * q_time device int32 [B]; hidden_dir [3*N_old, ld]; rela_dir [3*n_rela_rows, ld]; time_dir [3*n_time, ld].
+ * Scratch as rg_layer_fwd_scratch_bytes(). */
+int rg_tlayer_fwd(const rg_frontier* f, const rg_graph* g, int32_t level, int64_t n_new, const int32_t* q_time,
+                  const float* hidden_dir, const float* rela_dir, const float* time_dir, int32_t d, int32_t ld,
+                  const float* a_s, const float* a_r, const float* a_q, int32_t ap,
+                  const float* w_alpha, const float* b_alpha, int32_t attn_dim,
+                  float* agg_out, void* scratch_dev, size_t scratch_bytes, void* stream);
 
 /* ---- layer backward: adjoint of rg_layer_fwd (autograd of models.py:29-39) --------------------
  * grad_agg [N_new, ld].  grad_hidden [N_old, ld] and grad_a_s [N_old, ap] are WRITTEN (every row);

@@ -160,6 +160,65 @@ def forward(p, graph, subs, rels, n_layer, act="relu", dtype=torch.float32, trac
     return scores_all
 
 
+# --------------------------------------------------------------------------------------
+# temporal interpolation  (Temporal/interpolation/model_cuda.py:98-213, model.py:40-105)
+# --------------------------------------------------------------------------------------
+def temporal_forward(p, quads, n_ent, heads, rels, times, n_layer, act, shared_tables=False, dtype=torch.float32, trace=None):
+    """T_RED_GNN.forward in eval mode (no fact deletion, dropout = identity).
+
+    quads int [n,4] = (head, rel, tail, time id) incl. the identity rows, as graph.py:34-49 builds it.
+    ``shared_tables``: parameter layout of model.py (one rela_embed / attention_1 / attention_2, leaky_relu in the
+    reference) instead of model_cuda.py's per-layer tables.  Only model.py can be imported in the build container
+    (model_cuda.py needs tkinter.tix / pyvis / pickles), so the per-layer-table variant is pinned through the shared
+    per-edge arithmetic only: parity unpinned for what differs (which table a layer reads, the activation choice)."""
+    quads = np.asarray(quads, dtype=np.int64).reshape(-1, 4)
+    heads, rels, times = (np.asarray(x, dtype=np.int64) for x in (heads, rels, times))
+    n = len(heads)
+    g = lambda k: _t(p[k], dtype)
+    d = g("time_embed.weight").shape[1]
+    acts = {"tanh": torch.tanh, "sigmoid": torch.sigmoid, "relu": torch.relu, "idd": lambda x: x,
+            "softplus": torch.nn.functional.softplus, "leaky_relu": torch.nn.functional.leaky_relu}
+    actf = acts[act]
+    order = np.argsort(quads[:, 0], kind="stable")
+    ptr = np.zeros(n_ent + 1, dtype=np.int64)
+    np.add.at(ptr, quads[:, 0] + 1, 1)
+    ptr = np.cumsum(ptr)
+    cur = np.stack([np.arange(n), heads], 1)                        # model_cuda.py:108
+    hidden = torch.zeros(n, d, dtype=dtype)
+    qt = torch.as_tensor(times)
+    for i in range(n_layer):
+        if shared_tables:
+            rela, w1, w2 = g("rela_embed.weight"), g("attention_1.weight"), g("attention_2.weight")
+        else:
+            rela, w1, w2 = g("rela_embed_layer.%d.weight" % i), g("attention_1_layer.%d.weight" % i), g("attention_2_layer.%d.weight" % i)
+        deg = ptr[cur[:, 1] + 1] - ptr[cur[:, 1]]
+        node_of = np.repeat(np.arange(len(cur)), deg)               # :141-145  rows whose head is in the frontier of the same query
+        rows = order[np.repeat(ptr[cur[:, 1]], deg) + (np.arange(int(deg.sum())) - np.repeat(np.cumsum(deg) - deg, deg))]
+        sel = np.concatenate([cur[node_of, 0][:, None], quads[rows]], 1)        # (batch, head, rel, tail, time)
+        b_idx = torch.as_tensor(sel[:, 0])
+        rel_t = torch.as_tensor(sel[:, 2])
+        dt = torch.as_tensor(sel[:, 4]) - qt[b_idx]                 # :149
+        hs = hidden[torch.as_tensor(node_of)]
+        embed = hs + rela[rel_t] + g("time_embed.weight")[dt.abs()]             # :152
+        out = torch.zeros_like(embed)
+        out[dt > 0] = embed[dt > 0] @ g("future_linear.weight").T               # :155-157
+        out[dt == 0] = embed[dt == 0] @ g("now_linear.weight").T
+        out[dt < 0] = embed[dt < 0] @ g("past_linear.weight").T
+        att_in = torch.cat([hs, rela[rel_t], rela[torch.as_tensor(rels)][b_idx]], 1)      # :159
+        alpha = torch.sigmoid(torch.relu(att_in @ w1.T) @ w2.T)                 # :160
+        key = sel[:, 0] * n_ent + sel[:, 3]                         # :175 unique (batch, tail), sorted
+        uk, inv = np.unique(key, return_inverse=True)
+        agg = torch.zeros(len(uk), d, dtype=dtype).index_add_(0, torch.as_tensor(inv), alpha * out)   # :192
+        hidden = actf(agg)                                          # :196
+        cur = np.stack([uk // n_ent, uk % n_ent], 1)
+        if trace is not None:
+            trace.append(dict(nodes=cur, n_edges=len(sel), hidden=hidden))
+    result = (hidden @ g("linear_classifier.weight").T + g("linear_classifier.bias")).reshape(-1)   # :210
+    score_all = torch.zeros(n, n_ent, dtype=dtype)
+    score_all[torch.as_tensor(cur[:, 0]), torch.as_tensor(cur[:, 1])] = result
+    return score_all
+
+
 def loss_fn(scores, pos_tail):
     """base_model.py:58-60 — full-softmax cross entropy, restated literally.
 

@@ -11,7 +11,7 @@ import torch
 from torch.optim import Adam
 from torch.optim.lr_scheduler import ExponentialLR
 
-from .models import RED_GNN_trans
+from .models import RED_GNN_induc, RED_GNN_trans
 from .utils import cal_performance, cal_ranks_csr
 
 
@@ -25,7 +25,8 @@ def reference_loss(scores, tails):
 
 class BaseModel(object):
     def __init__(self, args, loader):
-        self.model = RED_GNN_trans(args, loader)
+        # the inductive loader (two graphs) pairs with RED_GNN_induc (Static/inductive/base_model.py:14)
+        self.model = (RED_GNN_induc if getattr(loader, "inductive", False) else RED_GNN_trans)(args, loader)
         self.model.cuda()
         self.loader = loader
         self.n_ent, self.n_rel = loader.n_ent, loader.n_rel
@@ -75,7 +76,7 @@ class BaseModel(object):
             batch_idx = np.arange(i * batch_size, min(n_data, (i + 1) * batch_size))
             subs, rels, ap, ai, fp, fi = self.loader.get_batch_csr(batch_idx, data=data)
             with torch.no_grad():
-                scores = self.model(subs, rels, mode=data)
+                scores = self.model(subs, rels, mode=self.loader.eval_mode(data) if hasattr(self.loader, "eval_mode") else data)
                 ranking.append(cal_ranks_csr(scores, ap, ai, fp, fi))
         return torch.cat(ranking).double().cpu().numpy()
 

@@ -174,6 +174,63 @@ extern "C" {
 const char* rg_last_error(void) { return rg::g_err.c_str(); }
 int rg_version(void) { return 1; }
 
+// rows (H, R, T [, TIME]) -> device CSRs, packed entries, virtual rows
+static int build_graph(int32_t n_ent, int32_t n_rel, int32_t n_rela_rows, const std::vector<int32_t>& H,
+                       const std::vector<int32_t>& R, const std::vector<int32_t>& T, const std::vector<int32_t>* TIME,
+                       int32_t n_time, rg_graph** out) {
+  const int64_t n_fact = (int64_t)H.size();
+  std::vector<int32_t> out_ptr(n_ent + 1, 0), in_ptr(n_ent + 1, 0);
+  for (int64_t i = 0; i < n_fact; ++i) { out_ptr[H[i] + 1]++; in_ptr[T[i] + 1]++; }
+  int32_t max_in = 0, max_out = 0;
+  for (int32_t e = 0; e < n_ent; ++e) {
+    max_out = out_ptr[e + 1] > max_out ? out_ptr[e + 1] : max_out;
+    max_in = in_ptr[e + 1] > max_in ? in_ptr[e + 1] : max_in;
+    out_ptr[e + 1] += out_ptr[e];
+    in_ptr[e + 1] += in_ptr[e];
+  }
+  std::vector<int2> out_rt(n_fact), in_hr(n_fact);
+  std::vector<int32_t> in_time(TIME ? n_fact : 0);
+  {
+    std::vector<int32_t> po(out_ptr.begin(), out_ptr.end() - 1), pi(in_ptr.begin(), in_ptr.end() - 1);
+    for (int64_t i = 0; i < n_fact; ++i) {  // stable: fact-row order inside each CSR row
+      out_rt[po[H[i]]++] = make_int2(R[i], T[i]);
+      const int32_t q = pi[T[i]]++;
+      in_hr[q] = make_int2(H[i], R[i]);
+      if (TIME) in_time[q] = (*TIME)[i];
+    }
+  }
+  rg_graph* g = new rg_graph();
+  g->n_ent = n_ent; g->n_rel = n_rel; g->n_rela_rows = n_rela_rows; g->n_time = n_time;
+  g->n_fact = n_fact; g->max_in_deg = max_in; g->max_out_deg = max_out;
+  auto fail = [&]() { rg_graph_destroy(g); return 1; };
+#define RG_HIP_G(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { rg::set_error("%s failed: %s", #expr, hipGetErrorString(e_)); return fail(); } } while (0)
+  RG_HIP_G(hipMalloc(&g->out_ptr, (n_ent + 1) * sizeof(int32_t)));
+  RG_HIP_G(hipMalloc(&g->in_ptr, (n_ent + 1) * sizeof(int32_t)));
+  RG_HIP_G(hipMalloc(&g->out_rt, std::max<int64_t>(n_fact, 1) * sizeof(int2)));
+  RG_HIP_G(hipMalloc(&g->in_hr, std::max<int64_t>(n_fact, 1) * sizeof(int2)));
+  RG_HIP_G(hipMemcpy(g->out_ptr, out_ptr.data(), (n_ent + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+  RG_HIP_G(hipMemcpy(g->in_ptr, in_ptr.data(), (n_ent + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+  RG_HIP_G(hipMemcpy(g->out_rt, out_rt.data(), n_fact * sizeof(int2), hipMemcpyHostToDevice));
+  RG_HIP_G(hipMemcpy(g->in_hr, in_hr.data(), n_fact * sizeof(int2), hipMemcpyHostToDevice));
+  if (TIME) {
+    RG_HIP_G(hipMalloc(&g->in_time, std::max<int64_t>(n_fact, 1) * sizeof(int32_t)));
+    RG_HIP_G(hipMemcpy(g->in_time, in_time.data(), n_fact * sizeof(int32_t), hipMemcpyHostToDevice));
+  }
+  if (n_ent <= (1 << 20) && n_rela_rows <= (1 << 12)) {
+    std::vector<uint32_t> pk(n_fact);
+    for (int64_t i = 0; i < n_fact; ++i) pk[i] = ((uint32_t)in_hr[i].y << 20) | (uint32_t)in_hr[i].x;
+    RG_HIP_G(hipMalloc(&g->in_pk, std::max<int64_t>(n_fact, 1) * sizeof(uint32_t)));
+    RG_HIP_G(hipMemcpy(g->in_pk, pk.data(), n_fact * sizeof(uint32_t), hipMemcpyHostToDevice));
+    for (int64_t i = 0; i < n_fact; ++i) pk[i] = ((uint32_t)out_rt[i].x << 20) | (uint32_t)out_rt[i].y;
+    RG_HIP_G(hipMalloc(&g->out_pk, std::max<int64_t>(n_fact, 1) * sizeof(uint32_t)));
+    RG_HIP_G(hipMemcpy(g->out_pk, pk.data(), n_fact * sizeof(uint32_t), hipMemcpyHostToDevice));
+  }
+#undef RG_HIP_G
+  if (build_vrows(in_ptr, n_ent, &g->in_vr) || build_vrows(out_ptr, n_ent, &g->out_vr)) return fail();
+  *out = g;
+  return 0;
+}
+
 int rg_graph_create(int32_t n_ent, int32_t n_rel, const int32_t* triples, int64_t n, int add_inverse,
                     rg_graph** out) {
   RG_CHECK(out != nullptr, "rg_graph_create: out is NULL");
@@ -194,49 +251,23 @@ int rg_graph_create(int32_t n_ent, int32_t n_rel, const int32_t* triples, int64_
   }
   const int64_t id0 = n_fact - n_ent;
   for (int32_t e = 0; e < n_ent; ++e) { H[id0 + e] = e; R[id0 + e] = 2 * n_rel; T[id0 + e] = e; }
+  return build_graph(n_ent, n_rel, 2 * n_rel + 1, H, R, T, nullptr, 0, out);
+}
 
-  std::vector<int32_t> out_ptr(n_ent + 1, 0), in_ptr(n_ent + 1, 0);
-  for (int64_t i = 0; i < n_fact; ++i) { out_ptr[H[i] + 1]++; in_ptr[T[i] + 1]++; }
-  int32_t max_in = 0, max_out = 0;
-  for (int32_t e = 0; e < n_ent; ++e) {
-    max_out = out_ptr[e + 1] > max_out ? out_ptr[e + 1] : max_out;
-    max_in = in_ptr[e + 1] > max_in ? in_ptr[e + 1] : max_in;
-    out_ptr[e + 1] += out_ptr[e];
-    in_ptr[e + 1] += in_ptr[e];
+int rg_tgraph_create(int32_t n_ent, int32_t n_rela_rows, int32_t n_time, const int32_t* quads, int64_t n, rg_graph** out) {
+  RG_CHECK(out != nullptr, "rg_tgraph_create: out is NULL");
+  *out = nullptr;
+  RG_CHECK(n_ent > 0 && n_rela_rows > 0 && n_time > 0, "rg_tgraph_create: n_ent=%d n_rela_rows=%d n_time=%d must be positive",
+           n_ent, n_rela_rows, n_time);
+  RG_CHECK(n >= 0 && n < ((int64_t)1 << 31) && (n == 0 || quads != nullptr), "rg_tgraph_create: bad quadruples (n=%lld)", (long long)n);
+  std::vector<int32_t> H(n), R(n), T(n), TM(n);
+  for (int64_t i = 0; i < n; ++i) {
+    const int32_t h = quads[4 * i], r = quads[4 * i + 1], t = quads[4 * i + 2], tm = quads[4 * i + 3];
+    RG_CHECK(h >= 0 && h < n_ent && t >= 0 && t < n_ent && r >= 0 && r < n_rela_rows && tm >= 0 && tm < n_time,
+             "rg_tgraph_create: quadruple %lld = (%d,%d,%d,%d) out of range", (long long)i, h, r, t, tm);
+    H[i] = h; R[i] = r; T[i] = t; TM[i] = tm;
   }
-  std::vector<int2> out_rt(n_fact), in_hr(n_fact);
-  {
-    std::vector<int32_t> po(out_ptr.begin(), out_ptr.end() - 1), pi(in_ptr.begin(), in_ptr.end() - 1);
-    for (int64_t i = 0; i < n_fact; ++i) {  // stable: fact-row order inside each CSR row
-      out_rt[po[H[i]]++] = make_int2(R[i], T[i]);
-      in_hr[pi[T[i]]++] = make_int2(H[i], R[i]);
-    }
-  }
-  rg_graph* g = new rg_graph();
-  g->n_ent = n_ent; g->n_rel = n_rel; g->n_fact = n_fact; g->max_in_deg = max_in; g->max_out_deg = max_out;
-  auto fail = [&]() { rg_graph_destroy(g); return 1; };
-#define RG_HIP_G(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { rg::set_error("%s failed: %s", #expr, hipGetErrorString(e_)); return fail(); } } while (0)
-  RG_HIP_G(hipMalloc(&g->out_ptr, (n_ent + 1) * sizeof(int32_t)));
-  RG_HIP_G(hipMalloc(&g->in_ptr, (n_ent + 1) * sizeof(int32_t)));
-  RG_HIP_G(hipMalloc(&g->out_rt, n_fact * sizeof(int2)));
-  RG_HIP_G(hipMalloc(&g->in_hr, n_fact * sizeof(int2)));
-  RG_HIP_G(hipMemcpy(g->out_ptr, out_ptr.data(), (n_ent + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
-  RG_HIP_G(hipMemcpy(g->in_ptr, in_ptr.data(), (n_ent + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
-  RG_HIP_G(hipMemcpy(g->out_rt, out_rt.data(), n_fact * sizeof(int2), hipMemcpyHostToDevice));
-  RG_HIP_G(hipMemcpy(g->in_hr, in_hr.data(), n_fact * sizeof(int2), hipMemcpyHostToDevice));
-  if (n_ent <= (1 << 20) && 2 * n_rel + 1 <= (1 << 12)) {
-    std::vector<uint32_t> pk(n_fact);
-    for (int64_t i = 0; i < n_fact; ++i) pk[i] = ((uint32_t)in_hr[i].y << 20) | (uint32_t)in_hr[i].x;
-    RG_HIP_G(hipMalloc(&g->in_pk, n_fact * sizeof(uint32_t)));
-    RG_HIP_G(hipMemcpy(g->in_pk, pk.data(), n_fact * sizeof(uint32_t), hipMemcpyHostToDevice));
-    for (int64_t i = 0; i < n_fact; ++i) pk[i] = ((uint32_t)out_rt[i].x << 20) | (uint32_t)out_rt[i].y;
-    RG_HIP_G(hipMalloc(&g->out_pk, n_fact * sizeof(uint32_t)));
-    RG_HIP_G(hipMemcpy(g->out_pk, pk.data(), n_fact * sizeof(uint32_t), hipMemcpyHostToDevice));
-  }
-#undef RG_HIP_G
-  if (build_vrows(in_ptr, n_ent, &g->in_vr) || build_vrows(out_ptr, n_ent, &g->out_vr)) return fail();
-  *out = g;
-  return 0;
+  return build_graph(n_ent, 0, n_rela_rows, H, R, T, &TM, n_time, out);
 }
 
 int rg_graph_destroy(rg_graph* g) {
@@ -247,6 +278,7 @@ int rg_graph_destroy(rg_graph* g) {
   if (g->in_hr) (void)hipFree(g->in_hr);
   if (g->in_pk) (void)hipFree(g->in_pk);
   if (g->out_pk) (void)hipFree(g->out_pk);
+  if (g->in_time) (void)hipFree(g->in_time);
   for (rg_vrows* v : {&g->in_vr, &g->out_vr}) {
     if (v->rows) (void)hipFree(v->rows);
     if (v->split) (void)hipFree(v->split);

@@ -389,7 +389,7 @@ extern "C" int rg_layer_bwd(const rg_frontier* f, const rg_graph* g, int32_t lev
   A.hidden = (const float4*)hidden; A.rela = (const float4*)rela; A.ld4 = ld / 4;
   A.a_s = (const float4*)a_s; A.a_r = (const float4*)a_r; A.a_q = (const float4*)a_q;
   A.w_alpha = w_alpha; A.b_alpha = b_alpha; A.attn_dim = attn_dim;
-  A.n_rela_rows = 2 * g->n_rel + 1;
+  A.n_rela_rows = g->n_rela_rows;
   A.grad_agg = (const float4*)grad_agg; A.g_hidden = (float4*)grad_hidden; A.g_rela = grad_rela;
   A.g_as = (float4*)grad_a_s; A.g_ar = grad_a_r; A.g_w = grad_w_alpha; A.g_b = grad_b_alpha;
   A.g_hidden_part = (float4*)scratch;

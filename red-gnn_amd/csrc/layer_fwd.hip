@@ -1,258 +1,5 @@
-// Fused relational message passing, forward.
-// Replaces GNNLayer.forward lines Static/transductive/models.py:29-39 — the five E x d gathers,
-// the attention MLP on E rows and torch_scatter.scatter(reduce='sum') — with ONE kernel that
-// never materialises an edge list or an E x d temporary:
-//
-//   for every query b and every virtual row (t, segment) of the KG's CSR-by-tail  [dense work space]:
-//     if (b,t) is in the new frontier (bitmap test; o = its popcount rank = node id):
-//       for every KG in-edge (h, r) -> t of the segment:
-//         if (b,h) is in the previous frontier:
-//           s      = rank of (b,h)
-//           alpha  = sigmoid(w . relu(a_s[s] + a_r[r] + a_q[b]) + b_alpha)
-//           acc   += alpha * (hidden[s] + rela[r])
-//       agg[o] = acc       (or a partial row when t is a hub cut into segments; combined in order below)
-//
-// Mapping (wave64), 1024-thread workgroups at <= 64 VGPRs (32 waves per CU hide the gather latency):
-//   * a destination item is owned by a group of G lanes, G*4 >= d floats, so a row is one coalesced
-//     float4 per lane (d=64: 16 lanes x 16 B = 256 B per row, 4 destinations per wave);
-//   * phase 1 runs lane-per-candidate (index math + attention scalar, G candidates at a time);
-//     surviving edges are compacted into a per-group LDS strip; phase 2 runs group-per-edge
-//     (row gather + FMA), four edges in flight per group;
-//   * virtual rows are sorted by length, so the groups of a wave have equal trip counts, and a hub
-//     of in-degree 17k is 133 independent items instead of one 17k-long serial loop;
-//   * the work space is query-major; XCD x (HW_REG_XCC_ID) serves the x-th eighth of it from its own
-//     in-order queue, one block step at a time: a 16-wave workgroup takes 64 consecutive items (DENSE:
-//     one per lane group; SPARSE: 1024, one lane tests one item and survivors are compacted), the
-//     next ticket is prefetched while the step runs.  An XCD's 64 resident workgroups therefore span
-//     at most 4096 consecutive items - a third of ONE query - whose hidden slab (<= n_ent*d*4 B)
-//     stays in that XCD's 4 MiB L2 while its destinations gather from it.  Queues only steer speed: a
-//     workgroup that finds its queue dry steals from the others, every item is processed once under
-//     any placement.
-// rela / a_r / w_alpha live in LDS.  Sums run in CSR order: bitwise reproducible.
-#include "walk.h"
-
-namespace {
-
-struct FwdArgs {
-  rg::WalkArgs walk;   // items tested against the NEW frontier (destinations)
-  const int2* in_hr;
-  const uint32_t* in_pk;
-  const int2* bm_old;
-  const int2* bm_new;
-  int W;
-  const float4* hidden;
-  const float4* rela;
-  int ld4;  // row stride of hidden / rela / agg in float4
-  const float4* a_s;
-  const float4* a_r;
-  const float4* a_q;
-  const float* w_alpha;
-  const float* b_alpha;
-  int attn_dim;
-  int n_rela_rows;
-  int rela_in_lds;
-  float4* agg;
-  float4* partial;
-};
-
-__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
-
-constexpr int FWD_BLOCK = 512;   // 3 workgroups per CU = 24 waves at <= 80 VGPRs (no spills)
-
-template <int G, int AP4, bool PACKED, bool DENSE, bool RELA_LDS>
-__global__ __launch_bounds__(FWD_BLOCK, 6) void layer_fwd_kernel(FwdArgs A) {
-  extern __shared__ float4 lds[];
-  constexpr int BLOCK = FWD_BLOCK;
-  constexpr int GW = 64 / G;                             // destination groups per wave
-  constexpr int WPB = BLOCK / 64;
-  float4* stage = lds;                                   // [BLOCK] edge tuples {s, r, alpha, -}
-  float4* ar_l = lds + BLOCK;                            // [n_rela_rows][AP4]
-  float4* w_l = ar_l + A.n_rela_rows * AP4;              // [AP4]
-  float4* rela_l = w_l + AP4;                            // [n_rela_rows][G] (optional)
-  int4* recs = reinterpret_cast<int4*>(rela_l + (RELA_LDS ? A.n_rela_rows * G : 0));   // [BLOCK] (SPARSE only)
-
-  for (int i = threadIdx.x; i < A.n_rela_rows * AP4; i += BLOCK) ar_l[i] = A.a_r[i];
-  if (threadIdx.x < AP4) {
-    float w[4];
-    for (int k = 0; k < 4; ++k) {
-      const int j = threadIdx.x * 4 + k;
-      w[k] = j < A.attn_dim ? A.w_alpha[j] : 0.f;
-    }
-    w_l[threadIdx.x] = make_float4(w[0], w[1], w[2], w[3]);
-  }
-  if constexpr (RELA_LDS) {
-    for (int i = threadIdx.x; i < A.n_rela_rows * G; i += BLOCK) {
-      const int r = i / G, c = i - r * G;
-      rela_l[i] = c < A.ld4 ? A.rela[(int64_t)r * A.ld4 + c] : f4zero();
-    }
-  }
-  __syncthreads();
-  const float b_alpha = A.b_alpha[0];
-
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int lane_g = lane & (G - 1), gi_w = lane / G;
-  float4* my_stage = stage + wv * 64 + gi_w * G;
-  const int gshift = lane & ~(G - 1);
-  const unsigned long long gmask = G == 64 ? ~0ull : ((1ull << G) - 1ull);
-  const bool row_lane = lane_g < A.ld4;
-  const int lane_c = row_lane ? lane_g : A.ld4 - 1;   // loads never branch: idle lanes re-read the last float4
-
-  // one destination item: sum over its candidate in-edges [beg, end) for query b
-  auto run_item = [&](int beg, int end, int b) -> float4 {
-    const float4* aq_p = A.a_q + (int64_t)b * AP4;
-    float4 aq[AP4 <= 2 ? AP4 : 1];
-    if constexpr (AP4 <= 2) {
-#pragma unroll
-      for (int k = 0; k < AP4; ++k) aq[k] = aq_p[k];
-    }
-    const int2* bm_row = A.bm_old + (int64_t)b * A.W;
-    float4 acc = f4zero();
-    for (int c0 = beg; c0 < end; c0 += G) {
-      // ---- phase 1: one candidate in-edge per lane ---------------------------------------------
-      const int c = c0 + lane_g;
-      bool valid = c < end;
-      int s = 0, r = 0;
-      float alpha = 0.f;
-      if (valid) {
-        int hd;
-        if constexpr (PACKED) { const uint32_t pk = A.in_pk[c]; hd = pk & 0xFFFFF; r = pk >> 20; }
-        else { const int2 hr = A.in_hr[c]; hd = hr.x; r = hr.y; }
-        const int2 wp = bm_row[hd >> 5];
-        const uint32_t word = (uint32_t)wp.x, bit = hd & 31;
-        valid = (word >> bit) & 1u;
-        if (valid) {
-          s = wp.y + __popc(word & ((1u << bit) - 1u));
-          float z = b_alpha;
-#pragma unroll
-          for (int k = 0; k < AP4; ++k) {
-            const float4 as = A.a_s[(int64_t)s * AP4 + k];
-            const float4 ar = ar_l[r * AP4 + k];
-            const float4 w = w_l[k];
-            float4 q;
-            if constexpr (AP4 <= 2) q = aq[k]; else q = aq_p[k];
-            z = fmaf(w.x, fmaxf(as.x + ar.x + q.x, 0.f), z);
-            z = fmaf(w.y, fmaxf(as.y + ar.y + q.y, 0.f), z);
-            z = fmaf(w.z, fmaxf(as.z + ar.z + q.z, 0.f), z);
-            z = fmaf(w.w, fmaxf(as.w + ar.w + q.w, 0.f), z);
-          }
-          alpha = __frcp_rn(1.0f + __expf(-z));
-        }
-      }
-      const unsigned long long m = (__ballot(valid) >> gshift) & gmask;
-      const int cnt = __popcll(m);
-      const int pos = __popcll(m & ((1ull << lane_g) - 1ull));
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // previous round's reads are done
-      __builtin_amdgcn_wave_barrier();
-      if (lane_g >= cnt) my_stage[lane_g] = f4zero();          // pad tuples: alpha = 0, row 0
-      if (valid) my_stage[pos] = make_float4(__int_as_float(s), __int_as_float(r), alpha, 0.f);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-
-      // ---- phase 2: one edge per group step, 4 row gathers in flight ---------------------------
-      for (int k = 0; k < cnt; k += 4) {
-        float4 tp[4], hv[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) tp[u] = my_stage[k + u];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-          hv[u] = A.hidden[(int64_t)__float_as_int(tp[u].x) * A.ld4 + lane_c];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int ru = __float_as_int(tp[u].y);
-          float4 rv;
-          if constexpr (RELA_LDS) rv = rela_l[ru * G + lane_g];
-          else rv = A.rela[(int64_t)ru * A.ld4 + lane_c];
-          const float al = tp[u].z;
-          acc.x = fmaf(al, hv[u].x + rv.x, acc.x);
-          acc.y = fmaf(al, hv[u].y + rv.y, acc.y);
-          acc.z = fmaf(al, hv[u].z + rv.z, acc.z);
-          acc.w = fmaf(al, hv[u].w + rv.w, acc.w);
-        }
-      }
-    }
-    return acc;
-  };
-  auto store_row = [&](int out, float4 acc) {
-    if (!row_lane) return;
-    if (out >= 0) A.agg[(int64_t)out * A.ld4 + lane_g] = acc;
-    else A.partial[(int64_t)(-out - 1) * A.ld4 + lane_g] = acc;
-  };
-  rg::walk_items<G, DENSE, BLOCK>(A.walk, recs, [&](const int4& R, bool live) {
-    const float4 acc = run_item(R.x, R.x + rg::walk_len(R), R.z);
-    if (live) store_row(rg::walk_out(R, A.walk.n_slots), acc);
-  });
-}
-
-// hubs cut into segments: agg[o] = sum of the segments' partial rows, in segment order
-__global__ void combine_kernel(const int4* __restrict__ split, int n_split, int n_slots, int B, const int2* __restrict__ bm_new,
-                               int W, const float4* __restrict__ partial, float4* __restrict__ agg, int ld4) {
-  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t item = tid / ld4;
-  const int c = (int)(tid - item * ld4);
-  if (item >= (int64_t)B * n_split) return;
-  const int b = (int)(item / n_split);
-  const int4 se = split[item - (int64_t)b * n_split];
-  const int2 wp = bm_new[(int64_t)b * W + (se.x >> 5)];
-  const uint32_t word = (uint32_t)wp.x, bit = se.x & 31;
-  if (!((word >> bit) & 1u)) return;
-  const int o = wp.y + __popc(word & ((1u << bit) - 1u));
-  const float4* p = partial + ((int64_t)b * n_slots + se.y) * ld4 + c;
-  float4 acc = p[0];
-  for (int k = 1; k < se.z; ++k) {
-    const float4 v = p[(int64_t)k * ld4];
-    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-  }
-  agg[(int64_t)o * ld4 + c] = acc;
-}
-
-template <int G, int AP4, bool PACKED, bool DENSE, bool RELA_LDS>
-int launch3(const FwdArgs& A, size_t lds, int B, const rg_vrows& vr, hipStream_t s) {
-  constexpr int BLOCK = FWD_BLOCK;
-  auto kern = layer_fwd_kernel<G, AP4, PACKED, DENSE, RELA_LDS>;
-  if (lds > 64 * 1024) RG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const int per_cu = lds <= 53 * 1024 ? 3 : (lds <= 80 * 1024 ? 2 : 1);
-  const int grid = rg::walk_grid(A.walk.n_items, BLOCK, G, DENSE, per_cu);
-  RG_HIP(hipMemsetAsync(A.walk.queues, 0, 8 * sizeof(int32_t), s));
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds, s, A);
-  RG_LAUNCH_CHECK();
-  if (vr.n_split > 0) {
-    const int64_t threads = (int64_t)B * vr.n_split * A.ld4;
-    hipLaunchKernelGGL(combine_kernel, dim3(rg::ceil_div(threads, 256)), dim3(256), 0, s, vr.split, vr.n_split, vr.n_slots, B,
-                       A.bm_new, A.W, A.partial, A.agg, A.ld4);
-    RG_LAUNCH_CHECK();
-  }
-  return 0;
-}
-
-template <int G, int AP4, bool PACKED, bool DENSE>
-int launch2(const FwdArgs& A, int B, const rg_vrows& vr, hipStream_t s) {
-  size_t lds = (size_t)(FWD_BLOCK + A.n_rela_rows * AP4 + AP4) * sizeof(float4);
-  if (!DENSE) lds += (size_t)FWD_BLOCK * sizeof(int4);
-  const size_t rela_bytes = (size_t)A.n_rela_rows * G * sizeof(float4);
-  RG_CHECK(lds <= 160 * 1024, "rg_layer_fwd: attention tables need %zu B of LDS (> 160 KiB)", lds);
-  if (lds + rela_bytes <= 53 * 1024) return launch3<G, AP4, PACKED, DENSE, true>(A, lds + rela_bytes, B, vr, s);   // 2 blocks per CU
-  return launch3<G, AP4, PACKED, DENSE, false>(A, lds, B, vr, s);
-}
-
-template <int G, int AP4>
-int launch(const FwdArgs& A, int B, const rg_vrows& vr, bool dense, hipStream_t s) {
-  if (A.in_pk) return dense ? launch2<G, AP4, true, true>(A, B, vr, s) : launch2<G, AP4, true, false>(A, B, vr, s);
-  return dense ? launch2<G, AP4, false, true>(A, B, vr, s) : launch2<G, AP4, false, false>(A, B, vr, s);
-}
-
-template <int G>
-int launch_ap(const FwdArgs& A, int ap4, int B, const rg_vrows& vr, bool dense, hipStream_t s) {
-  switch (ap4) {
-    case 1: return launch<G, 1>(A, B, vr, dense, s);
-    case 2: return launch<G, 2>(A, B, vr, dense, s);
-    case 3: return launch<G, 3>(A, B, vr, dense, s);
-    case 4: return launch<G, 4>(A, B, vr, dense, s);
-    case 8: return launch<G, 8>(A, B, vr, dense, s);
-    default: rg::set_error("rg_layer_fwd: padded attention dim %d not in {4,8,12,16,32}", ap4 * 4); return 1;
-  }
-}
-
-}  // namespace
+// Static RED-GNN entry point of the fused forward kernel (kernel: layer_fwd_kernel.h).
+#include "layer_fwd_kernel.h"
 
 extern "C" size_t rg_layer_fwd_scratch_bytes(const rg_frontier* f, const rg_graph* g, int32_t ld) {
   if (!f || !g) return 0;
@@ -264,40 +11,17 @@ extern "C" int rg_layer_fwd(const rg_frontier* f, const rg_graph* g, int32_t lev
                             const float* a_q, int32_t ap, const float* w_alpha, const float* b_alpha, int32_t attn_dim,
                             float* agg_out, void* scratch, size_t scratch_bytes, void* stream) {
   RG_CHECK(f && g && hidden && rela && a_s && a_r && a_q && w_alpha && b_alpha && agg_out, "rg_layer_fwd: NULL argument");
-  RG_CHECK(g->n_ent == f->n_ent, "rg_layer_fwd: graph has %d entities, frontier %d", g->n_ent, f->n_ent);
-  RG_CHECK(level >= 1 && level <= f->level && level > f->level - f->n_levels + 1,
-           "rg_layer_fwd: level %d not resident (current %d, %d kept)", level, f->level, f->n_levels);
-  RG_CHECK(n_new == f->n_nodes[level % f->n_levels], "rg_layer_fwd: n_new=%lld but level %d has %lld nodes",
-           (long long)n_new, level, (long long)f->n_nodes[level % f->n_levels]);
-  RG_CHECK(d > 0 && ld >= d && ld % 4 == 0 && ld >= 16 && ld <= 256, "rg_layer_fwd: d=%d ld=%d (need ld%%4==0, 16<=ld<=256)", d, ld);
-  RG_CHECK(attn_dim > 0 && ap >= attn_dim && ap % 4 == 0, "rg_layer_fwd: attn_dim=%d ap=%d", attn_dim, ap);
   RG_CHECK((((uintptr_t)hidden | (uintptr_t)rela | (uintptr_t)a_s | (uintptr_t)a_r | (uintptr_t)a_q | (uintptr_t)agg_out |
              (uintptr_t)scratch) & 15) == 0, "rg_layer_fwd: float buffers must be 16-B aligned");
-  const size_t need = rg_layer_fwd_scratch_bytes(f, g, ld);
-  RG_CHECK(g->in_vr.n_slots == 0 || (scratch && scratch_bytes >= need), "rg_layer_fwd: scratch %zu B < required %zu B",
-           scratch_bytes, need);
-  RG_CHECK((int64_t)f->B * std::max(g->in_vr.n_slots, 1) < ((int64_t)1 << 31) && g->in_vr.n_slots < (1 << 22),
-           "rg_layer_fwd: batch * hub segments overflows int32");
-  const int64_t n_items = (int64_t)f->B * g->in_vr.n;
+  rgfwd::FwdArgs A;
+  if (rgfwd::fill_common("rg_layer_fwd", f, g, level, n_new, d, ld, ap, attn_dim, scratch, scratch_bytes,
+                         rg_layer_fwd_scratch_bytes(f, g, ld), &A)) return 1;
   if (n_new == 0) return 0;
-  FwdArgs A;
-  A.walk.n_items = n_items; A.walk.n_vrows = g->in_vr.n; A.walk.n_slots = g->in_vr.n_slots; A.walk.vrows = g->in_vr.rows;
-  A.walk.bm_test = f->bm_of(level); A.walk.W = f->W; A.walk.queues = f->counters + 16;
-  A.in_hr = g->in_hr; A.in_pk = g->in_pk;
-  A.bm_old = f->bm_of(level - 1); A.bm_new = f->bm_of(level); A.W = f->W;
-  A.hidden = (const float4*)hidden; A.rela = (const float4*)rela; A.ld4 = ld / 4;
+  A.hidden = (const float4*)hidden; A.rela = (const float4*)rela;
   A.a_s = (const float4*)a_s; A.a_r = (const float4*)a_r; A.a_q = (const float4*)a_q;
-  A.w_alpha = w_alpha; A.b_alpha = b_alpha; A.attn_dim = attn_dim;
-  A.n_rela_rows = 2 * g->n_rel + 1; A.rela_in_lds = 0;
+  A.w_alpha = w_alpha; A.b_alpha = b_alpha;
   A.agg = (float4*)agg_out; A.partial = (float4*)scratch;
-  RG_CHECK(n_items / 8 + ((int64_t)1 << 26) < ((int64_t)1 << 31), "rg_layer_fwd: work space too large for 32-bit queue tickets");
-  hipStream_t s = (hipStream_t)stream;
   // dense walk when at least a quarter of all (query, entity) pairs are visited; else filter 64 items per wave
   const bool dense = n_new * 4 >= (int64_t)f->B * f->n_ent;
-  const int ld4 = ld / 4;
-  if (ld4 <= 4) return launch_ap<4>(A, ap / 4, f->B, g->in_vr, dense, s);
-  if (ld4 <= 8) return launch_ap<8>(A, ap / 4, f->B, g->in_vr, dense, s);
-  if (ld4 <= 16) return launch_ap<16>(A, ap / 4, f->B, g->in_vr, dense, s);
-  if (ld4 <= 32) return launch_ap<32>(A, ap / 4, f->B, g->in_vr, dense, s);
-  return launch_ap<64>(A, ap / 4, f->B, g->in_vr, dense, s);
+  return rgfwd::dispatch<false>(A, ld / 4, ap / 4, f->B, g->in_vr, dense, (hipStream_t)stream);
 }

@@ -63,6 +63,21 @@ class Graph:
             pass
 
 
+class TemporalGraph(Graph):
+    """Device-resident quadruple graph (head, rel, tail, time id) of T-RED-GNN (Temporal/interpolation/graph.py:34-49),
+    used as given: the reference's array already holds the identity rows with the sentinel timestamp."""
+
+    def __init__(self, n_ent, n_rela_rows, n_time, quads, device="cuda"):
+        self.device = _require_gpu(device)
+        q = np.ascontiguousarray(np.asarray(quads, dtype=np.int32).reshape(-1, 4))
+        self.n_ent, self.n_rel, self.n_rela_rows, self.n_time = int(n_ent), 0, int(n_rela_rows), int(n_time)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().rg_tgraph_create(self.n_ent, self.n_rela_rows, self.n_time, _lib.ptr(q), len(q), C.byref(h)))
+        self.handle = h
+        self.n_fact = int(_lib.lib().rg_graph_n_fact(h))
+
+
 class Frontier:
     """Per-batch visited-set state (levels of (batch, entity) node sets) in a torch-owned workspace.
     Replaces the state threaded through RED_GNN_trans.forward / DataLoader.get_neighbors
@@ -171,6 +186,22 @@ def layer_fwd(frontier, graph, level, nodes_new, hidden, rela, d, a_s, a_r, a_q,
     if ev is not None:
         ev[1].record()
         KERNEL_EVENTS.append((ev[0], ev[1], frontier.n_edges, n_new))
+    return agg
+
+
+def tlayer_fwd(frontier, graph, level, n_new, q_time, hidden_dir, rela_dir, time_dir, d, a_s, a_r, a_q, w_alpha, b_alpha, attn_dim):
+    """Temporal fused message passing (rg_tlayer_fwd): agg [n_new, ld]."""
+    ld, ap = hidden_dir.shape[1], a_s.shape[1]
+    for t in (hidden_dir, rela_dir, time_dir, a_s, a_r, a_q, w_alpha, b_alpha):
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+    assert q_time.dtype == torch.int32 and q_time.is_cuda
+    agg = torch.empty((n_new, ld), dtype=torch.float32, device=hidden_dir.device)
+    nbytes = _lib.lib().rg_layer_fwd_scratch_bytes(frontier.handle, graph.handle, ld)
+    scratch = frontier.scratch(nbytes)
+    _lib.check(_lib.lib().rg_tlayer_fwd(frontier.handle, graph.handle, level, n_new, _lib.ptr(q_time), _lib.ptr(hidden_dir),
+                                        _lib.ptr(rela_dir), _lib.ptr(time_dir), d, ld, _lib.ptr(a_s), _lib.ptr(a_r), _lib.ptr(a_q),
+                                        ap, _lib.ptr(w_alpha), _lib.ptr(b_alpha), attn_dim, _lib.ptr(agg), _lib.ptr(scratch),
+                                        nbytes, _lib.stream_ptr()))
     return agg
 
 

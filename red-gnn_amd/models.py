@@ -111,13 +111,13 @@ class RED_GNN_trans(nn.Module):
         self.last_stats = None
         self.fused_dense = True      # inference: W_h + GRU + projections + readout in one MFMA kernel (rg_dense_fwd)
 
-    def _frontier(self, batch, n_levels, device):
-        key = (batch, n_levels, str(device))
+    def _frontier(self, n_ent, batch, n_levels, device):
+        key = (n_ent, batch, n_levels, str(device))
         fr = self._frontiers.get(key)
         if fr is None:
             if len(self._frontiers) > 8:
                 self._frontiers.clear()
-            fr = self._frontiers[key] = engine.Frontier(self.loader.n_ent, batch, n_levels, device)
+            fr = self._frontiers[key] = engine.Frontier(n_ent, batch, n_levels, device)
         return fr
 
     def forward(self, subs, rels, mode="train", trace=None):
@@ -128,7 +128,8 @@ class RED_GNN_trans(nn.Module):
         q_sub = torch.as_tensor(np.asarray(subs), dtype=torch.int32).to(device)
         q_rel = torch.as_tensor(np.asarray(rels), dtype=torch.int64).to(device)
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
-        fr = self._frontier(n, self.n_layer + 1 if need_grad else 2, device)
+        n_ent = graph.n_ent                     # the inductive setting switches graphs (and n_ent) with the mode
+        fr = self._frontier(n_ent, n, self.n_layer + 1 if need_grad else 2, device)
         fr.reset(q_sub)
         if not need_grad and self.fused_dense and engine.dense_supported(self.hidden_dim, self.attn_dim):
             return self._forward_inference(fr, graph, q_sub, q_rel, n, device, trace)
@@ -152,17 +153,17 @@ class RED_GNN_trans(nn.Module):
                 trace.append(dict(nodes=nodes, old_nodes_new_idx=old_new, n_edges=n_e, hidden=hidden))
             nodes_old = nodes
         scores = self.W_final(hidden).squeeze(-1)                                # models.py:86
-        key = nodes_old[:, 0].long() * self.loader.n_ent + nodes_old[:, 1].long()
-        scores_all = torch.zeros(n * self.loader.n_ent, device=device).index_copy(0, key, scores)    # models.py:87-88
+        key = nodes_old[:, 0].long() * n_ent + nodes_old[:, 1].long()
+        scores_all = torch.zeros(n * n_ent, device=device).index_copy(0, key, scores)    # models.py:87-88
         self.last_stats = dict(n_edges=n_edges, n_nodes=int(nodes_old.shape[0]))
-        return scores_all.view(n, self.loader.n_ent)
+        return scores_all.view(n, n_ent)
 
     def _forward_inference(self, fr, graph, q_sub, q_rel, n, device, trace):
         """The same forward with no autograd graph: per layer one expansion, one fused message-passing
         kernel and one fused dense kernel; hidden / a_s never leave their padded device layout."""
         d, a = self.hidden_dim, self.attn_dim
         ld, ap = max(16, _pad4(d)), _pad4(a)
-        n_ent = self.loader.n_ent
+        n_ent = graph.n_ent
         hidden = torch.zeros((n, ld), device=device)
         a_s = torch.zeros((n, ap), device=device)                     # hidden == 0 at layer 0 (models.py:74)
         scores_all = torch.zeros(n * n_ent, device=device)           # models.py:87
@@ -183,3 +184,11 @@ class RED_GNN_trans(nn.Module):
                 trace.append(dict(nodes=nodes, old_nodes_new_idx=old_new, n_edges=n_e, hidden=hidden[:, :d]))
         self.last_stats = dict(n_edges=n_edges, n_nodes=int(nodes.shape[0]))
         return scores_all.view(n, n_ent)
+
+
+class RED_GNN_induc(RED_GNN_trans):
+    """Static/inductive/models.py:45-89: the same network; ``mode`` ('transductive' | 'inductive') selects the
+    graph and with it the entity count of the score matrix.  Use with ``red_gnn_amd.inductive.DataLoader``."""
+
+    def forward(self, subs, rels, mode="transductive", trace=None):
+        return super().forward(subs, rels, mode=mode, trace=trace)

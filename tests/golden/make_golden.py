@@ -37,6 +37,8 @@ _scatter_log = []
 
 def _scatter(src, index, dim=0, dim_size=None, reduce="sum"):
     assert dim == 0 and reduce == "sum"
+    if dim_size is None:                      # torch_scatter's default: index.max() + 1
+        dim_size = int(index.max()) + 1
     out = torch.zeros((dim_size,) + tuple(src.shape[1:]), dtype=src.dtype).index_add_(0, index, src)
     _scatter_log.append(out.detach().clone())
     return out
@@ -211,6 +213,94 @@ def case_dataset(out_dir, name, n_layer, dims, act, n_q, with_ids=True, light=Fa
         np.savez_compressed(os.path.join(out_dir, "%s_d%d.npz" % (name, d)), **rec)
 
 
+def case_inductive(out_dir, name="WN18RR_v1", d=32, n_layer=3, n_q=4):
+    """Static/inductive: same GNNLayer, two graphs (tra / ind), n_ent switches with the mode
+    (inductive/models.py:65-89, inductive/load_data.py:7-192)."""
+    import importlib.util
+    ind_dir = "/root/reference/Static/inductive"
+
+    def load(mod):
+        spec = importlib.util.spec_from_file_location("ref_ind_" + mod, os.path.join(ind_dir, mod + ".py"))
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        return m
+
+    ild, imodels = load("load_data"), load("models")
+    cwd = os.getcwd()
+    os.chdir(ind_dir)
+    loader = ild.DataLoader(os.path.join("data", name))
+    os.chdir(cwd)
+    ids = dict(n_ent=np.int64(loader.n_ent), n_rel=np.int64(loader.n_rel), n_ent_ind=np.int64(loader.n_ent_ind),
+               tra_kg=loader.tra_KG[:-loader.n_ent].astype(np.int32), ind_kg=loader.ind_KG[:-loader.n_ent_ind].astype(np.int32),
+               tra_valid=np.array(loader.tra_valid, dtype=np.int32), tra_test=np.array(loader.tra_test, dtype=np.int32),
+               ind_valid=np.array(loader.ind_valid, dtype=np.int32), ind_test=np.array(loader.ind_test, dtype=np.int32))
+    np.savez_compressed(os.path.join(out_dir, "ind_%s_ids.npz" % name), **ids)
+    params = make_params(n_layer, d, 5, loader.n_rel, "relu", dropout=0.0)
+    global ref_models
+    keep = ref_models
+    ref_models = imodels
+    imodels.RED_GNN_trans = imodels.RED_GNN_induc          # run_forward instantiates .RED_GNN_trans
+    try:
+        for mode, data, filt_d in (("transductive", "valid", loader.val_filters), ("inductive", "test", loader.tst_filters)):
+            q = loader.valid_q if data == "valid" else loader.test_q
+            a = loader.valid_a if data == "valid" else loader.test_a
+            n_ent = loader.n_ent if mode == "transductive" else loader.n_ent_ind
+            idx = list(range(n_q))
+            subs = np.array([q[i][0] for i in idx]); rels = np.array([q[i][1] for i in idx])
+            objs = np.zeros((n_q, n_ent)); filt = np.zeros((n_q, n_ent))
+            for k, i in enumerate(idx):
+                objs[k][a[i]] = 1
+                filt[k][np.array(filt_d[(subs[k], rels[k])])] = 1
+            _, scores, rec = run_forward(loader, params, subs, rels, mode)
+            rec = {k: v for k, v in rec.items() if not k.endswith(("_agg", "_layer_out"))}
+            rec["ranks"] = np.array(ref_utils.cal_ranks(scores.detach().numpy(), objs, filt))
+            rec["labels_idx"] = np.stack(np.nonzero(objs), 1).astype(np.int32)
+            rec["filters_idx"] = np.stack(np.nonzero(filt), 1).astype(np.int32)
+            np.savez_compressed(os.path.join(out_dir, "ind_%s_%s.npz" % (name, mode)), **rec)
+    finally:
+        ref_models = keep
+
+
+def case_temporal(out_dir):
+    """Temporal/interpolation/model.py (the importable T_RED_GNN: d=20, a=30, 3 layers, leaky_relu, shared tables)
+    on a synthetic quadruple graph shaped as graph.py:34-49 builds it (identity rows with the sentinel = largest
+    time id).  model_cuda.py (per-layer tables) cannot be imported here (tkinter.tix, pyvis, pickles)."""
+    import importlib.util
+    tdir = "/root/reference/Temporal/interpolation"
+    spec = importlib.util.spec_from_file_location("ref_temporal_model", os.path.join(tdir, "model.py"))
+    tm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tm)
+    rng = np.random.default_rng(11)
+    n_ent, n_rel, n_time, n_q = 60, 6, 365, 700          # relation ids 0..4 + idd (5): len(relation_vocab) = 6
+    h, t = rng.integers(0, n_ent, n_q), rng.integers(0, n_ent, n_q)
+    r, tau = rng.integers(0, n_rel - 1, n_q), rng.integers(0, n_time - 1, n_q)
+    tau[:40] = tau[40:80]                                 # some exact-same-day edges for the 'now' branch
+    quads = np.stack([h, r, t, tau], 1)
+    idd = np.stack([np.arange(n_ent), np.full(n_ent, n_rel - 1), np.arange(n_ent), np.full(n_ent, n_time - 1)], 1)
+    graph = np.concatenate([quads, idd], 0).astype(np.int64)
+
+    class Prm:
+        relation_vocab, entity_vocab, device = list(range(n_rel)), list(range(n_ent)), "cpu"
+    Prm.graph = graph
+    np.random.seed(1234)
+    torch.manual_seed(1234)
+    model = tm.T_RED_GNN(Prm).eval()
+    B = 6
+    batch = {"head": torch.as_tensor(quads[:B, 0]), "relation": torch.as_tensor(quads[:B, 1]), "time": torch.as_tensor(quads[40:40 + B, 3]),
+             "example_idx": torch.zeros(0, dtype=torch.long)}
+    _scatter_log.clear()
+    scores = model(batch)
+    rec = dict(quads=graph.astype(np.int32), n_ent=np.int64(n_ent), n_rel=np.int64(n_rel), n_time=np.int64(n_time),
+               heads=batch["head"].numpy().astype(np.int32), rels=batch["relation"].numpy().astype(np.int32),
+               times=batch["time"].numpy().astype(np.int32), scores=scores.detach().numpy(),
+               cfg=np.array([3, 20, 30], dtype=np.int64), act=np.array("leaky_relu"))
+    for i, a in enumerate(_scatter_log):
+        rec["L%d_agg" % i] = a.numpy()
+    for k, v in model.state_dict().items():
+        rec["param::" + k] = v.numpy()
+    np.savez_compressed(os.path.join(out_dir, "temporal_model_py.npz"), **rec)
+
+
 def case_ranks(out_dir):
     rng = np.random.default_rng(5)
     n, m = 12, 300
@@ -241,6 +331,8 @@ if __name__ == "__main__":
     case_dataset(out, "family", 3, [48, 64], "relu", 8)
     case_dataset(out, "umls", 4, [48], "relu", 4)
     case_dataset(out, "WN18RR", 5, [48], "tanh", 4, light=True)
+    case_inductive(out)
+    case_temporal(out)
     for f in sorted(os.listdir(out)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(out, f)))

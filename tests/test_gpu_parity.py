@@ -306,3 +306,82 @@ def test_training_learns_on_family():
     mrr1, out = bm.train_batch(epoch=0, max_batches=150)
     assert np.isfinite(bm.last_epoch_loss)
     assert mrr1 > max(0.5, 3 * mrr0), (mrr0, mrr1, out)
+
+
+@pytest.mark.parametrize("mode", ["transductive", "inductive"])
+def test_inductive_setting_matches_reference_fixture(mode):
+    """Static/inductive: two-graph loader, RED_GNN_induc; n_ent switches with the mode."""
+    from red_gnn_amd.inductive import DataLoader
+    from red_gnn_amd.models import RED_GNN_induc
+    from red_gnn_amd.utils import cal_ranks
+    fx, ids = U.load("ind_WN18RR_v1_%s.npz" % mode), U.load("ind_WN18RR_v1_ids.npz")
+    loader = DataLoader(ids=ids, verbose=False)
+    n_layer, d, a = (int(x) for x in fx["cfg"])
+    model = RED_GNN_induc(P(n_layer, d, a, loader.n_rel, str(fx["act"])), loader).cuda().eval()
+    model.load_state_dict({k: torch.tensor(v) for k, v in U.params_of(fx).items()}, strict=True)
+    trace = []
+    with torch.no_grad():
+        scores = model(fx["subs"], fx["rels"], mode=mode, trace=trace)
+    for i, t in enumerate(trace):
+        assert np.array_equal(t["nodes"].cpu().numpy(), fx["L%d_nodes" % i])
+        assert np.array_equal(t["old_nodes_new_idx"].cpu().numpy(), fx["L%d_old_nodes_new_idx" % i])
+        assert t["n_edges"] == int(fx["L%d_n_edges" % i])
+        np.testing.assert_allclose(t["hidden"].cpu().numpy(), fx["L%d_hidden" % i], rtol=RTOL, atol=ATOL_H)
+    n_ent = loader.n_ent if mode == "transductive" else loader.n_ent_ind
+    assert tuple(scores.shape) == (len(fx["subs"]), n_ent) == fx["scores"].shape
+    np.testing.assert_allclose(scores.cpu().numpy(), fx["scores"], rtol=RTOL, atol=ATOL)
+    labels = np.zeros(fx["scores"].shape); labels[fx["labels_idx"][:, 0], fx["labels_idx"][:, 1]] = 1
+    filt = np.zeros(fx["scores"].shape); filt[fx["filters_idx"][:, 0], fx["filters_idx"][:, 1]] = 1
+    assert np.array_equal(np.array(cal_ranks(fx["scores"], labels, filt)), fx["ranks"])
+    # loader parity: queries and filters as the reference built them
+    data = "valid" if mode == "transductive" else "test"
+    subs, rels, ap, ai, fp, fi = loader.get_batch_csr(np.arange(len(fx["subs"])), data=data)
+    assert np.array_equal(subs, fx["subs"]) and np.array_equal(rels, fx["rels"])
+    assert np.array_equal(ai.cpu().numpy(), fx["labels_idx"][:, 1]) and np.array_equal(fi.cpu().numpy(), fx["filters_idx"][:, 1])
+
+
+class TP:
+    pass
+
+
+def _temporal_model(fx, shared, n_layer, d, a, act, seed=None):
+    from red_gnn_amd.temporal import T_RED_GNN
+    p = TP()
+    p.n_rel, p.n_ent, p.n_time = int(fx["n_rel"]), int(fx["n_ent"]), int(fx["n_time"])
+    p.hidden_dim, p.attn_dim, p.n_layer, p.act, p.graph, p.device = d, a, n_layer, act, fx["quads"], "cuda"
+    if seed is not None:
+        torch.manual_seed(seed)
+    return T_RED_GNN(p, shared_tables=shared).cuda().eval()
+
+
+def test_temporal_matches_reference_model_py_fixture():
+    """T-RED-GNN interpolation forward (rg_tlayer_fwd) vs the output of the reference's model.py."""
+    fx = U.load("temporal_model_py.npz")
+    n_layer, d, a = (int(x) for x in fx["cfg"])
+    model = _temporal_model(fx, True, n_layer, d, a, str(fx["act"]))
+    model.load_state_dict({k: torch.tensor(v) for k, v in U.params_of(fx).items()}, strict=True)
+    s = model({"head": fx["heads"], "relation": fx["rels"], "time": fx["times"]}, mode="test").cpu().numpy()
+    np.testing.assert_allclose(s, fx["scores"], rtol=RTOL, atol=ATOL)
+    assert np.array_equal(s == 0, fx["scores"] == 0)
+
+
+@pytest.mark.parametrize("d,a,act,n_layer", [(64, 30, "relu", 3), (32, 5, "tanh", 4), (20, 30, "idd", 2)])
+def test_temporal_per_layer_tables_vs_oracle(d, a, act, n_layer):
+    """model_cuda.py's layout (per-layer relation / attention tables) on an ICEWS14-shaped synthetic graph with hubs,
+    against the oracle (this variant cannot be imported in the build container: parity pinned through model.py only)."""
+    rng = np.random.default_rng(3)
+    n_ent, n_rel, n_time, n_q = 400, 12, 365, 6000
+    w = 1.0 / np.arange(1, n_ent + 1); w /= w.sum()
+    h, t = rng.choice(n_ent, n_q, p=w), rng.integers(0, n_ent, n_q)
+    quads = np.stack([h, rng.integers(0, n_rel - 1, n_q), t, rng.integers(0, n_time - 1, n_q)], 1)
+    quads = np.concatenate([quads, quads[:, [2, 1, 0, 3]]], 0)                      # inverse direction keeps hubs as tails too
+    idd = np.stack([np.arange(n_ent), np.full(n_ent, n_rel - 1), np.arange(n_ent), np.full(n_ent, n_time - 1)], 1)
+    fx = dict(quads=np.concatenate([quads, idd], 0).astype(np.int32), n_ent=n_ent, n_rel=n_rel, n_time=n_time)
+    model = _temporal_model(fx, False, n_layer, d, a, act, seed=9)
+    B = 7
+    batch = {"head": quads[:B, 0], "relation": quads[:B, 1], "time": quads[:B, 3]}
+    s = model(batch, mode="test").cpu().numpy()
+    p = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    ref = orc.temporal_forward(p, fx["quads"], n_ent, batch["head"], batch["relation"], batch["time"], n_layer, act).numpy()
+    np.testing.assert_allclose(s, ref, rtol=RTOL, atol=ATOL_H)
+    assert np.array_equal(s == 0, ref == 0)

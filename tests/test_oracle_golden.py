@@ -93,3 +93,35 @@ def test_ranks_heavy_ties():
     assert np.array_equal(np.array(orc.cal_ranks(fx["scores"], lab, fil)), fx["ranks"])
     assert np.array_equal(np.array(orc.cal_ranks_closed_form(fx["scores"], lab, fil)), fx["ranks"])
     np.testing.assert_allclose(np.array(orc.cal_performance(fx["ranks"])), fx["perf"], rtol=1e-12)
+
+
+@pytest.mark.parametrize("mode", ["transductive", "inductive"])
+def test_inductive_fixture(mode):
+    """Static/inductive: same layer, two graphs; the oracle on the reference's own outputs."""
+    fx, ids = U.load("ind_WN18RR_v1_%s.npz" % mode), U.load("ind_WN18RR_v1_ids.npz")
+    n_rel = int(ids["n_rel"])
+    g = orc.OracleGraph(ids["tra_kg"], int(ids["n_ent"]), n_rel) if mode == "transductive" else \
+        orc.OracleGraph(ids["ind_kg"], int(ids["n_ent_ind"]), n_rel)
+    trace = []
+    scores = orc.forward(U.params_of(fx), g, fx["subs"], fx["rels"], int(fx["cfg"][0]), act=str(fx["act"]), trace=trace)
+    for i, t in enumerate(trace):
+        assert np.array_equal(t["nodes"], fx["L%d_nodes" % i])
+        assert np.array_equal(t["old_nodes_new_idx"], fx["L%d_old_nodes_new_idx" % i])
+        assert U.edge_multiset_hash(t["edges"]) == str(fx["L%d_edge_hash" % i])
+        np.testing.assert_allclose(t["hidden"].numpy(), fx["L%d_hidden" % i], rtol=RTOL, atol=ATOL)
+    assert scores.shape == fx["scores"].shape
+    np.testing.assert_allclose(scores.numpy(), fx["scores"], rtol=RTOL, atol=ATOL)
+
+
+def test_temporal_fixture_model_py():
+    """Temporal/interpolation/model.py run in the build container vs the oracle's restatement of the shared
+    per-edge arithmetic (relative-time embedding, past/now/future linears, attention, scatter-sum)."""
+    fx = U.load("temporal_model_py.npz")
+    trace = []
+    s = orc.temporal_forward(U.params_of(fx), fx["quads"], int(fx["n_ent"]), fx["heads"], fx["rels"], fx["times"],
+                             int(fx["cfg"][0]), str(fx["act"]), shared_tables=True, trace=trace)
+    for i, t in enumerate(trace):
+        np.testing.assert_allclose(t["hidden"].numpy(), torch.nn.functional.leaky_relu(torch.tensor(fx["L%d_agg" % i])).numpy(),
+                                   rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(s.numpy(), fx["scores"], rtol=RTOL, atol=ATOL)
+    assert np.array_equal(s.numpy() == 0, fx["scores"] == 0)
