@@ -256,7 +256,7 @@ def test_full_size_properties_c2():
         prev = nodes
 
 
-@pytest.mark.parametrize("d,a,act", [(64, 5, "relu"), (48, 5, "tanh"), (32, 3, "idd"), (20, 10, "relu"), (30, 16, "tanh")])
+@pytest.mark.parametrize("d,a,act", [(64, 5, "relu"), (48, 5, "tanh"), (32, 3, "idd"), (20, 10, "relu"), (30, 16, "tanh"), (128, 5, "relu")])
 def test_fused_dense_kernel_matches_torch_dense_path(d, a, act):
     """rg_dense_fwd (f32 MFMA: W_h + act + GRU + next a_s + readout) against the same model with the
     dense part in torch ops (rocBLAS + gru_cell): same nodes, hidden and scores."""
