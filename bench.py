@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--config", default="C2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="initialise the process group even at world size 1 (exercises the RCCL path on one GPU)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -85,9 +86,12 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from red_gnn_amd import engine
@@ -121,7 +125,7 @@ def main():
             ranks = cal_ranks_csr(scores, a_ptr, a_idx, f_ptr, f_idx)
             sums = torch.stack([(1.0 / ranks).sum(), (ranks <= 1).sum(), (ranks <= 10).sum(),
                                 torch.tensor(float(ranks.numel()), device=ranks.device)])
-            if world > 1:
+            if dist is not None:
                 scores = gather_scores(scores, dist)          # north star: RCCL all-gather of the score shards
                 sums = reduce_metrics(sums, dist)
         return sums, model.last_stats

@@ -199,6 +199,11 @@ static int build_graph(int32_t n_ent, int32_t n_rel, int32_t n_rela_rows, const 
       if (TIME) in_time[q] = (*TIME)[i];
     }
   }
+  // CSR-by-head rows ordered by relation: the backward kernel then sees runs of equal relation and adds one
+  // partial sum per run (not per edge) to the privatised relation gradient
+  for (int32_t e = 0; e < n_ent; ++e)
+    std::stable_sort(out_rt.begin() + out_ptr[e], out_rt.begin() + out_ptr[e + 1],
+                     [](const int2& a, const int2& b) { return a.x < b.x; });
   rg_graph* g = new rg_graph();
   g->n_ent = n_ent; g->n_rel = n_rel; g->n_rela_rows = n_rela_rows; g->n_time = n_time;
   g->n_fact = n_fact; g->max_in_deg = max_in; g->max_out_deg = max_out;

@@ -14,6 +14,8 @@
 //   dA_q[b] = sum of dA_s over the nodes of query b is left to the caller (a segment sum).
 // The projections a_s = H Ws^T etc. are differentiated by the caller (dense GEMMs).
 // Work distribution: walk.h (in-order per-XCD queues; grad_agg rows of the query being processed stay in L2).
+#include <stdlib.h>
+
 #include "walk.h"
 
 namespace {
@@ -43,6 +45,7 @@ struct BwdArgs {
   float* g_ar;            // [n_rela_rows][ap]
   float* g_w;
   float* g_b;
+  int diag;   // RG_BWD_DIAG (timing experiments only): bit 0 skips the dRel accumulation
 };
 
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -82,8 +85,11 @@ __global__ __launch_bounds__(BWD_BLOCK, 4) void layer_bwd_kernel(BwdArgs A) {
   float4* gar_l = w_l + AP4;                // [nr][AP4]   grad a_r
   float4* red_l = gar_l + nr * AP4;         // [(BLOCK/64)][AP4 + 1] block reduction of dw, db
   float4* rela_l = red_l + (BLOCK / 64) * (AP4 + 1);            // [nr][G]  (RELA_LDS)
-  float4* grela_l = rela_l + (RELA_LDS ? nr * G : 0);           // [nr][G]  (RELA_LDS)
-  int4* recs = reinterpret_cast<int4*>(grela_l + (RELA_LDS ? nr * G : 0));   // [BLOCK] (SPARSE only)
+  // grad rela, component-major inside a row and rows 8 floats apart in bank space: the 16 lanes of a group add to 16
+  // consecutive banks and four groups working on four different relations do not collide (ds_add_f32, 32 banks)
+  constexpr int RS = 4 * G + 8;
+  float* grela_l = reinterpret_cast<float*>(rela_l + (RELA_LDS ? nr * G : 0));   // [nr][RS]  (RELA_LDS)
+  int4* recs = reinterpret_cast<int4*>(grela_l + (RELA_LDS ? ((nr * RS + 3) & ~3) : 0));   // [BLOCK] (SPARSE only)
 
   for (int i = threadIdx.x; i < nr * AP4; i += BLOCK) { ar_l[i] = A.a_r[i]; gar_l[i] = f4zero(); }
   if (threadIdx.x < AP4) {
@@ -98,8 +104,8 @@ __global__ __launch_bounds__(BWD_BLOCK, 4) void layer_bwd_kernel(BwdArgs A) {
     for (int i = threadIdx.x; i < nr * G; i += BLOCK) {
       const int r = i / G, c = i - r * G;
       rela_l[i] = c < A.ld4 ? A.rela[(int64_t)r * A.ld4 + c] : f4zero();
-      grela_l[i] = f4zero();
     }
+    for (int i = threadIdx.x; i < nr * RS; i += BLOCK) grela_l[i] = 0.f;
   }
   __syncthreads();
   const float b_alpha = A.b_alpha[0];
@@ -128,6 +134,21 @@ __global__ __launch_bounds__(BWD_BLOCK, 4) void layer_bwd_kernel(BwdArgs A) {
     const float4 hs = A.hidden[(int64_t)s_node * A.ld4 + lane_c];
     const int2* bm_row = A.bm_new + (int64_t)b * A.W;
     float4 acc = f4zero();
+    // dRel: out-edges arrive sorted by relation, so alpha*G is summed in registers over a run of equal relation
+    // and added to the LDS copy once per run (float LDS atomics are the slowest thing in this kernel)
+    int run_r = -1;
+    float4 racc = f4zero();
+    auto flush_run = [&]() {
+      if (run_r >= 0 && row_lane && !(A.diag & 1)) {
+        if constexpr (RELA_LDS) {
+          float* gr = grela_l + run_r * RS + lane_g;
+          atomicAdd(gr, racc.x); atomicAdd(gr + G, racc.y); atomicAdd(gr + 2 * G, racc.z); atomicAdd(gr + 3 * G, racc.w);
+        } else {
+          float* gr = A.g_rela + ((int64_t)run_r * A.ld4 + lane_g) * 4;
+          atomicAdd(gr + 0, racc.x); atomicAdd(gr + 1, racc.y); atomicAdd(gr + 2, racc.z); atomicAdd(gr + 3, racc.w);
+        }
+      }
+    };
 
     for (int c0 = beg; c0 < end; c0 += G) {
       // ---- phase 1: one out-edge per lane: destination id, attention ----------------------------
@@ -165,15 +186,15 @@ __global__ __launch_bounds__(BWD_BLOCK, 4) void layer_bwd_kernel(BwdArgs A) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_wave_barrier();
 
-      // ---- phase 2: one edge per group step -------------------------------------------------------
-      for (int k = 0; k < cnt; k += 2) {
-        float4 tp[2], gv[2];
+      // ---- phase 2: one edge per group step, 4 grad rows in flight ------------------------------------
+      for (int k = 0; k < cnt; k += 4) {
+        float4 tp[4], gv[4];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) tp[u] = my_stage[k + u];
+        for (int u = 0; u < 4; ++u) tp[u] = my_stage[k + u];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) gv[u] = A.grad_agg[(int64_t)__float_as_int(tp[u].x) * A.ld4 + lane_c];
+        for (int u = 0; u < 4; ++u) gv[u] = A.grad_agg[(int64_t)__float_as_int(tp[u].x) * A.ld4 + lane_c];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < 4; ++u) {
           const float al = tp[u].z;
           const int ru = __float_as_int(tp[u].y);
           float4 rv;
@@ -190,11 +211,9 @@ __global__ __launch_bounds__(BWD_BLOCK, 4) void layer_bwd_kernel(BwdArgs A) {
           if (lane_g == 0) reinterpret_cast<float*>(&my_stage[k + u])[3] = dot;
           const float4 ag = make_float4(al * gv[u].x, al * gv[u].y, al * gv[u].z, al * gv[u].w);
           acc.x += ag.x; acc.y += ag.y; acc.z += ag.z; acc.w += ag.w;
-          if (al != 0.f && row_lane) {
-            float* gr;
-            if constexpr (RELA_LDS) gr = reinterpret_cast<float*>(&grela_l[ru * G + lane_g]);
-            else gr = A.g_rela + ((int64_t)ru * A.ld4 + lane_g) * 4;
-            atomicAdd(gr + 0, ag.x); atomicAdd(gr + 1, ag.y); atomicAdd(gr + 2, ag.z); atomicAdd(gr + 3, ag.w);
+          if (al != 0.f) {
+            if (ru != run_r) { flush_run(); run_r = ru; racc = f4zero(); }
+            racc.x += ag.x; racc.y += ag.y; racc.z += ag.z; racc.w += ag.w;
           }
         }
       }
@@ -224,6 +243,7 @@ __global__ __launch_bounds__(BWD_BLOCK, 4) void layer_bwd_kernel(BwdArgs A) {
         }
       }
     }
+    flush_run();
     // ---- per-source (or per-segment) results -------------------------------------------------------------
 #pragma unroll
     for (int k = 0; k < AP4; ++k) {
@@ -253,7 +273,7 @@ __global__ __launch_bounds__(BWD_BLOCK, 4) void layer_bwd_kernel(BwdArgs A) {
   if constexpr (RELA_LDS) {
     for (int i = threadIdx.x; i < nr * A.ld4 * 4; i += BLOCK) {
       const int r = i / (A.ld4 * 4), c = i - r * (A.ld4 * 4);
-      const float v = reinterpret_cast<float*>(grela_l)[r * G * 4 + c];
+      const float v = grela_l[r * RS + (c & 3) * G + (c >> 2)];
       if (v != 0.f) atomicAdd(A.g_rela + i, v);
     }
   }
@@ -327,7 +347,7 @@ template <int G, int AP4, bool PACKED, bool DENSE>
 int launch2(const BwdArgs& A, int B, const rg_vrows& vr, const int2* bm_old, hipStream_t s) {
   size_t lds = (size_t)(BWD_BLOCK + 2 * A.n_rela_rows * AP4 + AP4 + (BWD_BLOCK / 64) * (AP4 + 1)) * sizeof(float4);
   if (!DENSE) lds += (size_t)BWD_BLOCK * sizeof(int4);
-  const size_t rela_bytes = 2 * (size_t)A.n_rela_rows * G * sizeof(float4);
+  const size_t rela_bytes = (size_t)A.n_rela_rows * G * sizeof(float4) + (((size_t)A.n_rela_rows * (4 * G + 8) + 3) & ~(size_t)3) * sizeof(float);
   RG_CHECK(lds <= 160 * 1024, "rg_layer_bwd: attention tables need %zu B of LDS (> 160 KiB)", lds);
   if (lds + rela_bytes <= 80 * 1024) return launch3<G, AP4, PACKED, DENSE, true>(A, lds + rela_bytes, B, vr, bm_old, s);
   return launch3<G, AP4, PACKED, DENSE, false>(A, lds, B, vr, bm_old, s);
@@ -392,10 +412,13 @@ extern "C" int rg_layer_bwd(const rg_frontier* f, const rg_graph* g, int32_t lev
   A.n_rela_rows = g->n_rela_rows;
   A.grad_agg = (const float4*)grad_agg; A.g_hidden = (float4*)grad_hidden; A.g_rela = grad_rela;
   A.g_as = (float4*)grad_a_s; A.g_ar = grad_a_r; A.g_w = grad_w_alpha; A.g_b = grad_b_alpha;
+  { const char* e = getenv("RG_BWD_DIAG"); A.diag = e ? atoi(e) : 0; }
   A.g_hidden_part = (float4*)scratch;
   A.g_as_part = (float4*)((char*)scratch + rg::align_up((size_t)f->B * g->out_vr.n_slots * ld * sizeof(float), 256));
   hipStream_t s = (hipStream_t)stream;
-  const bool dense = n_old * 4 >= (int64_t)f->B * f->n_ent;
+  // every hop but the first walks densely: a sparse source set still carries hub rows of thousands of edges, and the
+  // 64-items-per-lane filter of the sparse walk hands them to a few workgroups (measured 10x slower on C2 hop 1)
+  const bool dense = n_old >= 4 * (int64_t)f->B;
   const int ld4 = ld / 4;
   const int2* bm_old = f->bm_of(level - 1);
   if (ld4 <= 4) return launch_ap<4>(A, ap / 4, f->B, g->out_vr, bm_old, dense, s);

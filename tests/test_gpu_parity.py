@@ -48,7 +48,7 @@ def test_library_version_and_graph_export():
     assert g.n_fact == og.n_fact == U.oracle_graph(ids, "test").n_fact
     op, ort, ip, ihr = g.export()
     assert np.array_equal(op, og.head_ptr)
-    kg = og.KG[og.rows_by_head]                  # rows grouped by head, fact order inside
+    kg = og.KG[np.lexsort((np.arange(og.n_fact), og.KG[:, 1], og.KG[:, 0]))]   # grouped by head, then relation, then fact order
     assert np.array_equal(ort, kg[:, [1, 2]])
     order_t = np.argsort(og.KG[:, 2], kind="stable")
     assert np.array_equal(ihr, og.KG[order_t][:, [0, 1]])
