@@ -43,7 +43,8 @@ def cpu_baseline(kg, shape, state, subs, rels, ans, filt, budget_s=20.0):
     """The oracle (CPU restatement, validated against the reference) on the host cores: same KG, same
     weights, the first queries of the same batch.  Bounded sample: batches of 4 queries until ~budget_s."""
     from oracle import redgnn_oracle as orc
-    torch.set_num_threads(os.cpu_count() or 1)
+    n_cpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(max(1, min(n_cpu, 64)))       # the cores this process may actually run on
     og = orc.OracleGraph(np.concatenate([orc.double_triple(kg.facts, kg.n_rel), orc.double_triple(kg.train, kg.n_rel)], 0),
                          kg.n_ent, kg.n_rel)
     p = {k: v.detach().cpu() for k, v in state.items()}
