@@ -385,3 +385,85 @@ def test_temporal_per_layer_tables_vs_oracle(d, a, act, n_layer):
     ref = orc.temporal_forward(p, fx["quads"], n_ent, batch["head"], batch["relation"], batch["time"], n_layer, act).numpy()
     np.testing.assert_allclose(s, ref, rtol=RTOL, atol=ATOL_H)
     assert np.array_equal(s == 0, ref == 0)
+
+
+# ---- edge cases ------------------------------------------------------------------------------------------------
+def _ids(n_ent, n_rel, facts, train=None, test=None):
+    z = np.zeros((0, 3), np.int64)
+    return dict(n_ent=n_ent, n_rel=n_rel, facts=np.asarray(facts, np.int64).reshape(-1, 3),
+                train=z if train is None else np.asarray(train, np.int64).reshape(-1, 3), valid=z,
+                test=z if test is None else np.asarray(test, np.int64).reshape(-1, 3))
+
+
+@pytest.mark.parametrize("n_ent,B", [(1, 1), (31, 1), (33, 3), (64, 33), (97, 65)])
+def test_edge_shapes_vs_oracle(n_ent, B):
+    """n_ent / batch sizes around the 32-bit word and 64-lane boundaries, isolated entities (identity edge only),
+    duplicate triples (kept as parallel edges, SURVEY §8 a4'), a graph with no triples at all (n_ent = 1)."""
+    from red_gnn_amd.load_data import DataLoader
+    rng = np.random.default_rng(n_ent * 131 + B)
+    n_rel = 3
+    m = 0 if n_ent == 1 else 4 * n_ent
+    h, t = rng.integers(0, max(n_ent - 2, 1), m), rng.integers(0, max(n_ent - 2, 1), m)     # the last entities stay isolated
+    facts = np.stack([h, rng.integers(0, n_rel, m), t], 1).reshape(-1, 3)
+    if m:
+        facts = np.concatenate([facts, facts[:5]], 0)                                        # duplicates
+    ids = _ids(n_ent, n_rel, facts)
+    loader = DataLoader(ids=ids, verbose=False)
+    model = _random_model(loader, 3, 32, 5, "relu", seed=3)
+    subs = rng.integers(0, n_ent, B)
+    subs[-1] = n_ent - 1                                                                     # an isolated query subject
+    rels = rng.integers(0, 2 * n_rel, B)
+    trace, otrace = [], []
+    with torch.no_grad():
+        s = model(subs, rels, mode="test", trace=trace).cpu().numpy()
+    p = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    ref = orc.forward(p, U.oracle_graph(ids, "test"), subs, rels, 3, act="relu", trace=otrace).numpy()
+    for a, b in zip(trace, otrace):
+        assert np.array_equal(a["nodes"].cpu().numpy(), b["nodes"])
+        assert a["n_edges"] == len(b["edges"])
+    np.testing.assert_allclose(s, ref, rtol=RTOL, atol=ATOL)
+    assert np.array_equal(s == 0, ref == 0)
+    # the same through the reference-compatible get_neighbors, hop by hop, incl. duplicated edges
+    nodes = np.stack([np.arange(B), subs], 1)
+    og = U.oracle_graph(ids, "test")
+    for _ in range(2):
+        t_nodes, t_edges, t_old = orc.get_neighbors(og, nodes)
+        g_nodes, g_edges, g_old = loader.get_neighbors(nodes, mode="test")
+        assert np.array_equal(g_nodes.cpu().numpy(), t_nodes) and np.array_equal(g_old.cpu().numpy(), t_old)
+        assert np.array_equal(U.sorted_edges(g_edges.cpu().numpy()), U.sorted_edges(t_edges))
+        nodes = t_nodes
+
+
+def test_bad_inputs_raise():
+    from red_gnn_amd import _lib
+    from red_gnn_amd.load_data import DataLoader
+    ids = _ids(10, 2, [[0, 0, 1], [1, 1, 2]])
+    loader = DataLoader(ids=ids, verbose=False)
+    model = _random_model(loader, 2, 16, 3, "relu")
+    with pytest.raises(_lib.NativeError):
+        model(np.array([0, 10]), np.array([0, 1]), mode="test")          # subject id == n_ent
+    with pytest.raises(_lib.NativeError):
+        loader.get_neighbors(np.array([[0, 1], [0, 1]]), mode="test")    # duplicate start nodes
+    with pytest.raises(_lib.NativeError):
+        DataLoader(ids=_ids(10, 2, [[0, 5, 1]]), verbose=False).graph    # relation id out of range
+    s = model(np.array([0, 9]), np.array([0, 3]), mode="test")           # still usable after the errors
+    assert torch.isfinite(s).all()
+
+
+def test_large_batch_property_checksum():
+    """BASELINE-size check without the oracle: sum over queries of scores is invariant to the order of the queries in
+    the batch (per-query independence + deterministic per-destination sums), B = 512 on C2."""
+    from red_gnn_amd.load_data import DataLoader
+    from red_gnn_amd.synthetic import make_shape
+    kg = make_shape("C2")
+    ids = dict(n_ent=kg.n_ent, n_rel=kg.n_rel, facts=kg.facts, train=kg.train, valid=kg.valid, test=kg.test)
+    loader = DataLoader(ids=ids, verbose=False)
+    model = _random_model(loader, 3, 64, 5, "relu")
+    B = 512
+    subs, rels = kg.test[:B, 0], kg.test[:B, 1]
+    perm = np.random.default_rng(0).permutation(B)
+    with torch.no_grad():
+        s1 = model(subs, rels, mode="test")
+        s2 = model(subs[perm], rels[perm], mode="test")
+    np.testing.assert_allclose(s2.cpu().numpy(), s1[perm].cpu().numpy(), rtol=RTOL, atol=ATOL)
+    assert torch.equal(s2 == 0, s1[perm] == 0)
