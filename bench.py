@@ -120,6 +120,8 @@ def main():
     if not args.no_kernel_events:
         engine.KERNEL_EVENTS = kernel_events
 
+    pending = []     # the previous step's all-gather (RCCL stream): it overlaps the next step's kernels
+
     def step():
         with torch.no_grad():
             scores = model(subs, rels, mode="test")
@@ -127,7 +129,10 @@ def main():
             sums = torch.stack([(1.0 / ranks).sum(), (ranks <= 1).sum(), (ranks <= 10).sum(),
                                 torch.tensor(float(ranks.numel()), device=ranks.device)])
             if dist is not None:
-                scores = gather_scores(scores, dist)          # north star: RCCL all-gather of the score shards
+                while pending:
+                    pending.pop()[0].wait()
+                # north star: RCCL all-gather of the score shards over xGMI; asynchronous, joined one step later
+                pending.append(gather_scores(scores, dist, async_op=True) + (scores,))
                 sums = reduce_metrics(sums, dist)
         return sums, model.last_stats
 
@@ -142,6 +147,8 @@ def main():
     for _ in range(args.steps):
         sums, st = step()
         edges += sum(st["n_edges"])
+    while pending:
+        pending.pop()[0].wait()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()

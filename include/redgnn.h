@@ -141,7 +141,7 @@ int rg_layer_bwd(const rg_frontier* f, const rg_graph* g, int32_t level, int64_t
  * W_h [d,d], weight_ih_l0 / weight_hh_l0 [3d,d] (gate rows r,z,n), bias_* [3d], Ws_next [attn,d] or NULL,
  * W_final [d] or NULL.  agg [n,ld], hidden_prev [n_old,ld], prev_idx int32 [n] (-1 = new node; NULL = all
  * new), a_s_out [n,ap], nodes int32 [n,2], scores_all [B*n_ent] (pre-zeroed; only visited entries are
- * written), hidden_out [n,ld].  act: 0 identity, 1 relu, 2 tanh.  Supported: d <= 64, attn_dim <= 16
+ * written), hidden_out [n,ld].  act: 0 identity, 1 relu, 2 tanh.  Supported: d <= 64 or d == 128, attn_dim <= 16
  * (rg_dense_fwd_supported); other shapes return an error and the caller keeps its own dense path. */
 int rg_dense_fwd_supported(int32_t d, int32_t attn_dim);
 int rg_dense_fwd(int64_t n, int32_t d, int32_t ld, const float* agg, const float* hidden_prev,

@@ -46,11 +46,12 @@ struct DenseArgs {
   int n_tiles;
 };
 
-// v_exp_f32 / v_rcp_f32 forms (1 ulp each): far inside the 1e-4 relative tolerance of the path
-__device__ __forceinline__ float fast_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+// v_exp_f32 / v_rcp_f32 forms (1 ulp each; __builtin_amdgcn_rcpf, not the correctly rounded __frcp_rn which expands
+// to a full division): far inside the 1e-4 relative tolerance of the path
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float fast_tanh(float x) {
   const float e = __expf(-2.0f * fabsf(x));            // in (0, 1]: no overflow
-  return copysignf((1.0f - e) * __frcp_rn(1.0f + e), x);
+  return copysignf((1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e), x);
 }
 
 // LDS images: rows of DP floats, 16-B slot index XOR-swizzled with the row so that 16 lanes reading the same
@@ -195,6 +196,10 @@ __global__ __launch_bounds__(dense_cfg<NB>::T, dense_cfg<NB>::WPS) void dense_ke
     }
   };
 
+  // The two waves of a SIMD run the same program; started together they stay in lockstep (both in the MFMA phase,
+  // then both in the transcendental/store phase, the matrix pipe idle).  Delaying the second half of the workgroup
+  // by about half an MFMA phase lets one wave's epilogue run under the other's MFMAs (MI355X_MICROARCH.md, item 9).
+  if (NW > 4 && wv >= NW / 2) __builtin_amdgcn_s_sleep(127);
   float4 va[NL], vh[NL];
   bool has_old = false;
   const int t_step = gridDim.x * NW;

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(BWD_BLOCK, 4) void layer_bwd_kernel(BwdArgs A) {
           z = fmaf(w.z, zr[k].z, z);
           z = fmaf(w.w, zr[k].w, z);
         }
-        alpha = __frcp_rn(1.0f + __expf(-z));
+        alpha = __builtin_amdgcn_rcpf(1.0f + __expf(-z));
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_wave_barrier();

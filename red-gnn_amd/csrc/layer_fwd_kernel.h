@@ -144,7 +144,7 @@ __global__ __launch_bounds__(FWD_BLOCK, 6) void layer_fwd_kernel(FwdArgs A) {
             z = fmaf(w.z, fmaxf(as.z + ar.z + q.z, 0.f), z);
             z = fmaf(w.w, fmaxf(as.w + ar.w + q.w, 0.f), z);
           }
-          alpha = __frcp_rn(1.0f + __expf(-z));
+          alpha = __builtin_amdgcn_rcpf(1.0f + __expf(-z));
           if constexpr (TEMPORAL) {
             // direction-specific linears hoisted per node / relation / |dt|: row = 3*id + dir, dir = past 0 / now 1 / future 2
             // (Temporal/interpolation/model_cuda.py:149-157)

@@ -32,13 +32,16 @@ def shard_by_cost(costs, world):
     return [sorted(p) for p in parts]
 
 
-def gather_scores(local_scores, dist, sizes=None):
-    """All-gather of [b_r, n_ent] score shards into [sum b_r, n_ent] on every rank (rank order)."""
+def gather_scores(local_scores, dist, sizes=None, async_op=False):
+    """All-gather of [b_r, n_ent] score shards into [sum b_r, n_ent] on every rank (rank order).
+    ``async_op=True`` returns (work, out): the collective runs on the RCCL stream and overlaps whatever the
+    caller launches next; call work.wait() before reading ``out`` (and keep ``local_scores`` alive until then)."""
     world = dist.get_world_size()
     if sizes is None:
         out = torch.empty((world * local_scores.shape[0], local_scores.shape[1]), dtype=local_scores.dtype, device=local_scores.device)
-        dist.all_gather_into_tensor(out, local_scores.contiguous())
-        return out
+        work = dist.all_gather_into_tensor(out, local_scores.contiguous(), async_op=async_op)
+        return (work, out) if async_op else out
+    assert not async_op
     bufs = [torch.empty((s, local_scores.shape[1]), dtype=local_scores.dtype, device=local_scores.device) for s in sizes]
     dist.all_gather(bufs, local_scores.contiguous())
     return torch.cat(bufs, 0)

@@ -47,7 +47,8 @@ def test_argument_errors_are_reported_not_fatal():
     assert b"out of range" in lib.rg_last_error()
     assert lib.rg_frontier_create(1 << 20, 1 << 12, 2, None, 0, C.byref(h)) != 0     # B*n_ent >= 2^31
     assert b"int32" in lib.rg_last_error()
-    assert lib.rg_dense_fwd_supported(64, 5) == 1 and lib.rg_dense_fwd_supported(128, 5) == 0
+    assert lib.rg_dense_fwd_supported(64, 5) == 1 and lib.rg_dense_fwd_supported(128, 5) == 1
+    assert lib.rg_dense_fwd_supported(96, 5) == 0 and lib.rg_dense_fwd_supported(64, 30) == 0
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
