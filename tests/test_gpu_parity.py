@@ -467,3 +467,34 @@ def test_large_batch_property_checksum():
         s2 = model(subs[perm], rels[perm], mode="test")
     np.testing.assert_allclose(s2.cpu().numpy(), s1[perm].cpu().numpy(), rtol=RTOL, atol=ATOL)
     assert torch.equal(s2 == 0, s1[perm] == 0)
+
+
+def test_five_adam_steps_track_the_oracle():
+    """Drop-in check of the whole training step: 5 x (forward, the reference's loss, HIP backward, Adam) with
+    dropout 0 leave the parameters where the same steps through the oracle (CPU autograd) leave them."""
+    from red_gnn_amd.base_model import reference_loss
+    from red_gnn_amd.load_data import DataLoader
+    from red_gnn_amd.models import RED_GNN_trans
+    from red_gnn_amd.synthetic import make_synthetic_kg
+    kg = make_synthetic_kg(300, 5, 2500, seed=17)
+    ids = dict(n_ent=kg.n_ent, n_rel=kg.n_rel, facts=kg.facts, train=kg.train, valid=kg.valid, test=kg.test)
+    loader = DataLoader(ids=ids, verbose=False)
+    torch.manual_seed(3)
+    model = RED_GNN_trans(P(3, 32, 5, loader.n_rel, "relu"), loader).cuda().train()
+    ref = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.named_parameters()}
+    opt = torch.optim.Adam(model.parameters(), lr=2e-3, weight_decay=1e-5)
+    ropt = torch.optim.Adam(list(ref.values()), lr=2e-3, weight_decay=1e-5)
+    og = U.oracle_graph(ids, "train")
+    for step in range(5):
+        trip = loader.train_data[step * 10:(step + 1) * 10]
+        opt.zero_grad()
+        loss = reference_loss(model(trip[:, 0], trip[:, 1]), torch.as_tensor(trip[:, 2], device="cuda"))
+        loss.backward()
+        opt.step()
+        ropt.zero_grad()
+        rloss = orc.loss_fn(orc.forward(ref, og, trip[:, 0], trip[:, 1], 3, act="relu"), trip[:, 2])
+        rloss.backward()
+        ropt.step()
+        assert abs(loss.item() - rloss.item()) < 2e-3 * abs(rloss.item()), (step, loss.item(), rloss.item())
+    for k, v in model.named_parameters():
+        np.testing.assert_allclose(v.detach().cpu().numpy(), ref[k].detach().numpy(), rtol=5e-3, atol=2e-4, err_msg=k)
