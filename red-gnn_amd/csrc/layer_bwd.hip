@@ -121,7 +121,7 @@ __global__ __launch_bounds__(BWD_BLOCK, 4) void layer_bwd_kernel(BwdArgs A) {
   for (int k = 0; k < AP4; ++k) gw[k] = f4zero();
   float gb = 0.f;
 
-  rg::walk_items<G, DENSE, BLOCK>(A.walk, recs, [&](const int4& R, bool live) {
+  rg::walk_items<G, DENSE, 1, BLOCK>(A.walk, recs, [&](const int4& R, bool live) {
     const int beg = R.x, end = R.x + rg::walk_len(R), b = R.z, s_node = R.w;
     float4 base[AP4], gas[AP4];
 #pragma unroll
@@ -330,7 +330,7 @@ int launch3(const BwdArgs& A, size_t lds, int B, const rg_vrows& vr, const int2*
   auto kern = layer_bwd_kernel<G, AP4, PACKED, DENSE, RELA_LDS>;
   if (lds > 64 * 1024) RG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int per_cu = lds <= 80 * 1024 ? 2 : 1;
-  const int grid = rg::walk_grid(A.walk.n_items, BWD_BLOCK, G, DENSE, per_cu);
+  const int grid = rg::walk_grid(A.walk.n_items, BWD_BLOCK, G, DENSE, per_cu, 1);
   RG_HIP(hipMemsetAsync(A.walk.queues, 0, 8 * sizeof(int32_t), s));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(BWD_BLOCK), lds, s, A);
   RG_LAUNCH_CHECK();

@@ -66,7 +66,7 @@ __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0
 
 constexpr int FWD_BLOCK = 512;   // 3 workgroups per CU = 24 waves at <= 80 VGPRs (no spills)
 
-template <int G, int AP4, bool PACKED, bool DENSE, bool RELA_LDS, bool TEMPORAL>
+template <int G, int AP4, bool PACKED, bool DENSE, int KPG, bool RELA_LDS, bool TEMPORAL>
 __global__ __launch_bounds__(FWD_BLOCK, 6) void layer_fwd_kernel(FwdArgs A) {
   extern __shared__ float4 lds[];
   constexpr int BLOCK = FWD_BLOCK;
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(FWD_BLOCK, 6) void layer_fwd_kernel(FwdArgs A) {
     if (out >= 0) A.agg[(int64_t)out * A.ld4 + lane_g] = acc;
     else A.partial[(int64_t)(-out - 1) * A.ld4 + lane_g] = acc;
   };
-  rg::walk_items<G, DENSE, BLOCK>(A.walk, recs, [&](const int4& R, bool live) {
+  rg::walk_items<G, DENSE, KPG, BLOCK>(A.walk, recs, [&](const int4& R, bool live) {
     const float4 acc = run_item(R.x, R.x + rg::walk_len(R), R.z);
     if (live) store_row(rg::walk_out(R, A.walk.n_slots), acc);
   });
@@ -227,13 +227,13 @@ __global__ void combine_kernel(const int4* __restrict__ split, int n_split, int 
   agg[(int64_t)o * ld4 + c] = acc;
 }
 
-template <int G, int AP4, bool PACKED, bool DENSE, bool RELA_LDS, bool TEMPORAL>
+template <int G, int AP4, bool PACKED, bool DENSE, int KPG, bool RELA_LDS, bool TEMPORAL>
 int launch3(const FwdArgs& A, size_t lds, int B, const rg_vrows& vr, hipStream_t s) {
   constexpr int BLOCK = FWD_BLOCK;
-  auto kern = layer_fwd_kernel<G, AP4, PACKED, DENSE, RELA_LDS, TEMPORAL>;
+  auto kern = layer_fwd_kernel<G, AP4, PACKED, DENSE, KPG, RELA_LDS, TEMPORAL>;
   if (lds > 64 * 1024) RG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int per_cu = lds <= 53 * 1024 ? 3 : (lds <= 80 * 1024 ? 2 : 1);
-  const int grid = rg::walk_grid(A.walk.n_items, BLOCK, G, DENSE, per_cu);
+  const int grid = rg::walk_grid(A.walk.n_items, BLOCK, G, DENSE, per_cu, KPG);
   RG_HIP(hipMemsetAsync(A.walk.queues, 0, 8 * sizeof(int32_t), s));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds, s, A);
   RG_LAUNCH_CHECK();
@@ -246,32 +246,40 @@ int launch3(const FwdArgs& A, size_t lds, int B, const rg_vrows& vr, hipStream_t
   return 0;
 }
 
-template <int G, int AP4, bool PACKED, bool DENSE, bool TEMPORAL>
-int launch2(const FwdArgs& A, int B, const rg_vrows& vr, hipStream_t s) {
+template <int G, int AP4, bool PACKED, bool DENSE, int KPG, bool TEMPORAL>
+int launch2k(const FwdArgs& A, int B, const rg_vrows& vr, hipStream_t s) {
   size_t lds = (size_t)(FWD_BLOCK + A.n_rela_rows * AP4 + AP4) * sizeof(float4);
   if (!DENSE) lds += (size_t)FWD_BLOCK * sizeof(int4);
   const size_t rela_bytes = (size_t)A.n_rela_rows * G * sizeof(float4);
   RG_CHECK(lds <= 160 * 1024, "rg_layer_fwd: attention tables need %zu B of LDS (> 160 KiB)", lds);
   if constexpr (!TEMPORAL) {   // the temporal relation table has 3x the rows: left in L2
-    if (lds + rela_bytes <= 53 * 1024) return launch3<G, AP4, PACKED, DENSE, true, false>(A, lds + rela_bytes, B, vr, s);   // 3 blocks per CU
+    if (lds + rela_bytes <= 53 * 1024) return launch3<G, AP4, PACKED, DENSE, KPG, true, false>(A, lds + rela_bytes, B, vr, s);   // 3 blocks per CU
   }
-  return launch3<G, AP4, PACKED, DENSE, false, TEMPORAL>(A, lds, B, vr, s);
+  return launch3<G, AP4, PACKED, DENSE, KPG, false, TEMPORAL>(A, lds, B, vr, s);
+}
+
+template <int G, int AP4, bool PACKED, bool DENSE, bool TEMPORAL>
+int launch2(const FwdArgs& A, int B, const rg_vrows& vr, int kpg, hipStream_t s) {
+  if constexpr (DENSE) {
+    if (kpg > 1) return launch2k<G, AP4, PACKED, true, rg::RG_KPG_SHORT, TEMPORAL>(A, B, vr, s);
+  }
+  return launch2k<G, AP4, PACKED, DENSE, 1, TEMPORAL>(A, B, vr, s);
 }
 
 template <int G, int AP4, bool TEMPORAL>
-int launch(const FwdArgs& A, int B, const rg_vrows& vr, bool dense, hipStream_t s) {
-  if (A.in_pk) return dense ? launch2<G, AP4, true, true, TEMPORAL>(A, B, vr, s) : launch2<G, AP4, true, false, TEMPORAL>(A, B, vr, s);
-  return dense ? launch2<G, AP4, false, true, TEMPORAL>(A, B, vr, s) : launch2<G, AP4, false, false, TEMPORAL>(A, B, vr, s);
+int launch(const FwdArgs& A, int B, const rg_vrows& vr, bool dense, int kpg, hipStream_t s) {
+  if (A.in_pk) return dense ? launch2<G, AP4, true, true, TEMPORAL>(A, B, vr, kpg, s) : launch2<G, AP4, true, false, TEMPORAL>(A, B, vr, kpg, s);
+  return dense ? launch2<G, AP4, false, true, TEMPORAL>(A, B, vr, kpg, s) : launch2<G, AP4, false, false, TEMPORAL>(A, B, vr, kpg, s);
 }
 
 template <int G, bool TEMPORAL>
-int launch_ap(const FwdArgs& A, int ap4, int B, const rg_vrows& vr, bool dense, hipStream_t s) {
+int launch_ap(const FwdArgs& A, int ap4, int B, const rg_vrows& vr, bool dense, int kpg, hipStream_t s) {
   switch (ap4) {
-    case 1: return launch<G, 1, TEMPORAL>(A, B, vr, dense, s);
-    case 2: return launch<G, 2, TEMPORAL>(A, B, vr, dense, s);
-    case 3: return launch<G, 3, TEMPORAL>(A, B, vr, dense, s);
-    case 4: return launch<G, 4, TEMPORAL>(A, B, vr, dense, s);
-    case 8: return launch<G, 8, TEMPORAL>(A, B, vr, dense, s);
+    case 1: return launch<G, 1, TEMPORAL>(A, B, vr, dense, kpg, s);
+    case 2: return launch<G, 2, TEMPORAL>(A, B, vr, dense, kpg, s);
+    case 3: return launch<G, 3, TEMPORAL>(A, B, vr, dense, kpg, s);
+    case 4: return launch<G, 4, TEMPORAL>(A, B, vr, dense, kpg, s);
+    case 8: return launch<G, 8, TEMPORAL>(A, B, vr, dense, kpg, s);
     default: rg::set_error("rg_layer_fwd: padded attention dim %d not in {4,8,12,16,32}", ap4 * 4); return 1;
   }
 }
@@ -302,12 +310,12 @@ inline int fill_common(const char* who, const rg_frontier* f, const rg_graph* g,
 }
 
 template <bool TEMPORAL>
-int dispatch(const FwdArgs& A, int ld4, int ap4, int B, const rg_vrows& vr, bool dense, hipStream_t s) {
-  if (ld4 <= 4) return launch_ap<4, TEMPORAL>(A, ap4, B, vr, dense, s);
-  if (ld4 <= 8) return launch_ap<8, TEMPORAL>(A, ap4, B, vr, dense, s);
-  if (ld4 <= 16) return launch_ap<16, TEMPORAL>(A, ap4, B, vr, dense, s);
-  if (ld4 <= 32) return launch_ap<32, TEMPORAL>(A, ap4, B, vr, dense, s);
-  return launch_ap<64, TEMPORAL>(A, ap4, B, vr, dense, s);
+int dispatch(const FwdArgs& A, int ld4, int ap4, int B, const rg_vrows& vr, bool dense, int kpg, hipStream_t s) {
+  if (ld4 <= 4) return launch_ap<4, TEMPORAL>(A, ap4, B, vr, dense, kpg, s);
+  if (ld4 <= 8) return launch_ap<8, TEMPORAL>(A, ap4, B, vr, dense, kpg, s);
+  if (ld4 <= 16) return launch_ap<16, TEMPORAL>(A, ap4, B, vr, dense, kpg, s);
+  if (ld4 <= 32) return launch_ap<32, TEMPORAL>(A, ap4, B, vr, dense, kpg, s);
+  return launch_ap<64, TEMPORAL>(A, ap4, B, vr, dense, kpg, s);
 }
 
 }  // namespace

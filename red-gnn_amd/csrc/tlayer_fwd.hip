@@ -26,5 +26,5 @@ extern "C" int rg_tlayer_fwd(const rg_frontier* f, const rg_graph* g, int32_t le
   A.agg = (float4*)agg_out; A.partial = (float4*)scratch;
   A.in_time = g->in_time; A.q_time = q_time; A.n_time = g->n_time; A.time_tab = (const float4*)time_dir;
   const bool dense = n_new * 4 >= (int64_t)f->B * f->n_ent;
-  return rgfwd::dispatch<true>(A, ld / 4, ap / 4, f->B, g->in_vr, dense, (hipStream_t)stream);
+  return rgfwd::dispatch<true>(A, ld / 4, ap / 4, f->B, g->in_vr, dense, rg::walk_kpg(g->n_fact, g->in_vr.n), (hipStream_t)stream);
 }

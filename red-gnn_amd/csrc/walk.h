@@ -26,6 +26,11 @@ struct WalkArgs {
   int32_t* queues;   // [8] item offsets inside each eighth, zeroed before the launch
 };
 
+// DENSE walks take KPG items per lane group and block step: 1 for graphs of long rows (C2: 34 entries per row),
+// RG_KPG_SHORT for graphs of short rows (WN18RR-like: 5 entries per row), where a block step of one 3-edge item per
+// group is all barrier and load latency.  A template value, so the one-item walk keeps its constant-folded form.
+constexpr int RG_KPG_SHORT = 8;
+
 __device__ __forceinline__ int walk_len(const int4& R) { return R.y & 255; }
 // row index of the item's result: >= 0 node id (whole entity), < 0: -(partial row) - 1
 __device__ __forceinline__ int walk_out(const int4& R, int n_slots) {
@@ -34,10 +39,10 @@ __device__ __forceinline__ int walk_out(const int4& R, int n_slots) {
 }
 
 // run_item(const int4& R, bool live) is called by all 64 lanes of a wave with one item per group of G lanes.
-template <int G, bool DENSE, int BLOCK, typename F>
+template <int G, bool DENSE, int KPG, int BLOCK, typename F>
 __device__ __forceinline__ void walk_items(const WalkArgs& A, int4* recs, F&& run_item) {
   constexpr int GW = 64 / G, WPB = BLOCK / 64;
-  constexpr int STEP = WPB * (DENSE ? GW : 64);
+  constexpr int STEP = DENSE ? WPB * GW * KPG : WPB * 64;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, gi_w = lane / G;
 
   auto test_item = [&](int b, int vr, int4& rec) -> bool {
@@ -78,13 +83,16 @@ __device__ __forceinline__ void walk_items(const WalkArgs& A, int4* recs, F&& ru
     if (threadIdx.x == 0) next_off = atomicAdd(&A.queues[q], STEP);     // prefetch the next ticket
 
     if constexpr (DENSE) {
-      const int idx = wv * GW + gi_w;
-      int b = b0, vr = vr0 + idx;
-      while (vr >= A.n_vrows) { vr -= A.n_vrows; ++b; }
-      int4 R = make_int4(0, 0, 0, 0);
-      const bool live = idx < cnt_items && test_item(b, vr, R);
-      if (!live) { R.x = 0; R.y = 0; }
-      run_item(R, live);
+#pragma unroll 1
+      for (int k = 0; k < KPG; ++k) {          // consecutive items go to different groups: equal lengths side by side
+        const int idx = k * (WPB * GW) + wv * GW + gi_w;
+        int b = b0, vr = vr0 + idx;
+        while (vr >= A.n_vrows) { vr -= A.n_vrows; ++b; }
+        int4 R = make_int4(0, 0, 0, 0);
+        const bool live = idx < cnt_items && test_item(b, vr, R);
+        if (!live) { R.x = 0; R.y = 0; }
+        run_item(R, live);
+      }
     } else {
       const int idx = wv * 64 + lane;
       int b = b0, vr = vr0 + idx;
@@ -110,9 +118,14 @@ __device__ __forceinline__ void walk_items(const WalkArgs& A, int4* recs, F&& ru
   }
 }
 
-// grid and queue reset for a walk launch
-static inline int walk_grid(int64_t n_items, int block, int g, bool dense, int per_cu) {
-  const int64_t steps = ceil_div(n_items, (int64_t)(block / 64) * (dense ? 64 / g : 64));
+// items per lane group and block step in the dense walk: about 24 CSR entries' worth of rows
+static inline int walk_kpg(int64_t n_fact, int32_t n_vrows) {
+  return (double)n_fact / std::max(n_vrows, 1) < 12.0 ? RG_KPG_SHORT : 1;
+}
+
+// grid for a walk launch
+static inline int walk_grid(int64_t n_items, int block, int g, bool dense, int per_cu, int kpg) {
+  const int64_t steps = ceil_div(n_items, (int64_t)(block / 64) * (dense ? (64 / g) * kpg : 64));
   return (int)std::max<int64_t>(std::min<int64_t>(steps, 256 * per_cu), 1);
 }
 
