@@ -55,11 +55,10 @@ class BaseModel(object):
             loss = reference_loss(scores, torch.as_tensor(triple[:, 2], dtype=torch.long, device=scores.device))
             loss.backward()
             self.optimizer.step()
-            # avoid NaN (base_model.py:64-69)
+            # avoid NaN (base_model.py:64-69): one numpy draw per parameter, as the reference consumes them, but as a
+            # masked fill on the device (no host synchronisation per parameter)
             for p in self.model.parameters():
-                flag = p.data != p.data
-                if flag.any():
-                    p.data[flag] = np.random.random()
+                p.data.masked_fill_(p.data != p.data, np.random.random())
             epoch_loss += loss.item()
         self.scheduler.step()
         self.t_time += time.time() - t_time
