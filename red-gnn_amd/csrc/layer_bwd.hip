@@ -294,7 +294,7 @@ __global__ __launch_bounds__(BWD_BLOCK, 4) void layer_bwd_kernel(BwdArgs A) {
     float v = 0.f;
     for (int w = 0; w < BLOCK / 64; ++w) v += red[w * (AP4 * 4 + 4) + threadIdx.x];
     if (threadIdx.x == AP4 * 4) { if (v != 0.f) atomicAdd(A.g_b, v); }
-    else if (threadIdx.x < A.attn_dim && v != 0.f) atomicAdd(A.g_w + threadIdx.x, v);
+    else if ((int)threadIdx.x < A.attn_dim && v != 0.f) atomicAdd(A.g_w + threadIdx.x, v);
   }
 }
 

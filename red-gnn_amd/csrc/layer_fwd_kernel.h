@@ -70,8 +70,6 @@ template <int G, int AP4, bool PACKED, bool DENSE, int KPG, bool RELA_LDS, bool 
 __global__ __launch_bounds__(FWD_BLOCK, 6) void layer_fwd_kernel(FwdArgs A) {
   extern __shared__ float4 lds[];
   constexpr int BLOCK = FWD_BLOCK;
-  constexpr int GW = 64 / G;                             // destination groups per wave
-  constexpr int WPB = BLOCK / 64;
   float4* stage = lds;                                   // [BLOCK] edge tuples {s, r, alpha, -}
   float4* ar_l = lds + BLOCK;                            // [n_rela_rows][AP4]
   float4* w_l = ar_l + A.n_rela_rows * AP4;              // [AP4]
