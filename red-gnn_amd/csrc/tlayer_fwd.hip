@@ -14,6 +14,7 @@ extern "C" int rg_tlayer_fwd(const rg_frontier* f, const rg_graph* g, int32_t le
   RG_CHECK(f && g && q_time && hidden_dir && rela_dir && time_dir && a_s && a_r && a_q && w_alpha && b_alpha && agg_out,
            "rg_tlayer_fwd: NULL argument");
   RG_CHECK(g->in_time && g->n_time > 0, "rg_tlayer_fwd: the graph has no timestamps (build it with rg_tgraph_create)");
+  RG_CHECK((int64_t)f->B * f->n_ent * 3 < ((int64_t)1 << 31), "rg_tlayer_fwd: 3 * batch * n_ent does not fit int32 row ids");
   RG_CHECK((((uintptr_t)hidden_dir | (uintptr_t)rela_dir | (uintptr_t)time_dir | (uintptr_t)a_s | (uintptr_t)a_r |
              (uintptr_t)a_q | (uintptr_t)agg_out | (uintptr_t)scratch) & 15) == 0, "rg_tlayer_fwd: float buffers must be 16-B aligned");
   rgfwd::FwdArgs A;
