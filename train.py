@@ -33,18 +33,20 @@ def main():
     parser.add_argument("--seed", type=int, default=1234)
     parser.add_argument("--gpu", type=int, default=int(os.environ.get("LOCAL_RANK", "0")))
     parser.add_argument("--epochs", type=int, default=50)
+    parser.add_argument("--ids", type=str, default=None, help="npz of pre-parsed id triples (n_ent, n_rel, facts, train, valid, test) instead of text files")
+    parser.add_argument("--preset", type=str, default=None, help="hyper-parameter preset name (default: the dataset directory name)")
     args = parser.parse_args()
 
     np.random.seed(args.seed)
     torch.manual_seed(args.seed)
-    dataset = [p for p in args.data_path.split("/") if p][-1]
+    dataset = args.preset or [p for p in args.data_path.split("/") if p][-1]
     os.makedirs("results", exist_ok=True)
     opts = Options()
     opts.perf_file = os.path.join("results", dataset + "_perf.txt")
     torch.cuda.set_device(args.gpu)
     print("gpu:", args.gpu)
 
-    loader = DataLoader(args.data_path)
+    loader = DataLoader(ids=dict(np.load(args.ids))) if args.ids else DataLoader(args.data_path)
     opts.n_ent, opts.n_rel = loader.n_ent, loader.n_rel
     (opts.lr, opts.decay_rate, opts.lamb, opts.hidden_dim, opts.attn_dim, opts.n_layer, opts.dropout, opts.act,
      opts.n_batch, opts.n_tbatch) = PRESETS.get(dataset, PRESETS["family"])
