@@ -498,3 +498,41 @@ def test_five_adam_steps_track_the_oracle():
         assert abs(loss.item() - rloss.item()) < 2e-3 * abs(rloss.item()), (step, loss.item(), rloss.item())
     for k, v in model.named_parameters():
         np.testing.assert_allclose(v.detach().cpu().numpy(), ref[k].detach().numpy(), rtol=5e-3, atol=2e-4, err_msg=k)
+
+
+def test_random_graphs_fuzz_vs_oracle():
+    """Forty small random graphs / batches / widths in one process: node sets bit-exact, scores within tolerance.
+    Catches indexing mistakes that fixed shapes miss (segment boundaries at 128, word boundaries, empty frontiers)."""
+    from red_gnn_amd.load_data import DataLoader
+    rng = np.random.default_rng(2024)
+    for case in range(40):
+        n_ent = int(rng.integers(2, 400))
+        n_rel = int(rng.integers(1, 9))
+        m = int(rng.integers(0, 12 * n_ent))
+        hub = int(rng.integers(0, n_ent))
+        h, t = rng.integers(0, n_ent, m), rng.integers(0, n_ent, m)
+        if case % 3 == 0 and m:
+            t[: m // 2] = hub                      # one hub with an in-row cut into segments
+        if case % 5 == 0 and m:
+            h[m // 2:] = hub
+        facts = np.stack([h, rng.integers(0, n_rel, m), t], 1).reshape(-1, 3)
+        ids = _ids(n_ent, n_rel, facts[: (3 * m) // 4], train=facts[(3 * m) // 4:])
+        loader = DataLoader(ids=ids, verbose=False)
+        d = int(rng.choice([16, 20, 32, 48, 64]))
+        a = int(rng.choice([3, 5, 8]))
+        n_layer = int(rng.integers(1, 5))
+        act = str(rng.choice(["relu", "tanh", "idd"]))
+        model = _random_model(loader, n_layer, d, a, act, seed=case)
+        B = int(rng.integers(1, 40))
+        subs, rels = rng.integers(0, n_ent, B), rng.integers(0, 2 * n_rel, B)
+        mode = "train" if case % 2 else "test"
+        trace, otrace = [], []
+        with torch.no_grad():
+            s = model(subs, rels, mode=mode, trace=trace).cpu().numpy()
+        p = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        ref = orc.forward(p, U.oracle_graph(ids, mode), subs, rels, n_layer, act=act, trace=otrace).numpy()
+        for x, y in zip(trace, otrace):
+            assert np.array_equal(x["nodes"].cpu().numpy(), y["nodes"]), case
+            assert x["n_edges"] == len(y["edges"]), case
+        np.testing.assert_allclose(s, ref, rtol=RTOL, atol=ATOL_H, err_msg="case %d" % case)
+        assert np.array_equal(s == 0, ref == 0), case

@@ -1,0 +1,40 @@
+"""Eval forward of the temporal variant on the ICEWS14-shaped synthetic of BASELINE configs[4] (C5)."""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from red_gnn_amd.synthetic import SHAPES
+from red_gnn_amd.temporal import T_RED_GNN
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+sh = SHAPES["C5"]
+rng = np.random.default_rng(1234)
+n_ent, n_rel_base, n_time, n_q = sh["n_ent"], 230, 365, sh["n_triples"]
+perm = rng.permutation(n_ent)
+w = 1.0 / np.arange(1, n_ent + 1); w /= w.sum()
+def ent(n):
+    return np.where(rng.random(n) < 0.5, perm[rng.choice(n_ent, n, p=w)], rng.integers(0, n_ent, n))
+h, t = ent(n_q), ent(n_q)
+r = rng.integers(0, n_rel_base, n_q); tau = rng.integers(0, n_time, n_q)
+quads = np.stack([h, r, t, tau], 1)
+inv = np.stack([t, r + n_rel_base, h, tau], 1)                       # '~' inverse relations
+n_rel = 2 * n_rel_base + 1                                           # + idd
+idd = np.stack([np.arange(n_ent), np.full(n_ent, n_rel - 1), np.arange(n_ent), np.full(n_ent, n_time)], 1)   # sentinel = largest time id
+
+
+class P:
+    pass
+
+
+p = P()
+p.n_rel, p.n_ent, p.n_time = n_rel, n_ent, n_time + 1
+p.hidden_dim, p.attn_dim, p.n_layer, p.act, p.device = sh["hidden_dim"], sh["attn_dim"], sh["n_layer"], "relu", "cuda"
+p.graph = np.concatenate([quads, inv, idd], 0)
+torch.manual_seed(0)
+model = T_RED_GNN(p).cuda().eval()
+batch = {"head": quads[:B, 0], "relation": quads[:B, 1], "time": quads[:B, 3]}
+for it in range(4):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    s = model(batch, mode="test")
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    e = sum(model.last_stats["n_edges"])
+    print("C5 temporal B=%d it%d: %.2f ms, edges %.3g per hop %s -> %.3g edges/s" % (B, it, dt * 1e3, e, model.last_stats["n_edges"], e / dt))
