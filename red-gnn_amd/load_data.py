@@ -18,10 +18,12 @@ from .engine import Frontier, Graph, _require_gpu
 
 
 class DataLoader:
-    def __init__(self, task_dir=None, ids=None, device="cuda", verbose=True):
+    def __init__(self, task_dir=None, ids=None, device="cuda", verbose=True, cache_dir=None):
         self.task_dir = task_dir
         self.device = torch.device(device)
         self.filters = defaultdict(set)
+        if ids is None and cache_dir is not None:
+            ids = self._cached_ids(task_dir, cache_dir)      # binary id cache of the parsed text
         if ids is None:
             self._read_text(task_dir)
         else:
@@ -48,6 +50,22 @@ class DataLoader:
         self._frontiers = {}
         if verbose:
             print("n_train:", self.n_train, "n_valid:", self.n_valid, "n_test:", self.n_test)
+
+    _FILES = ("entities.txt", "relations.txt", "facts.txt", "train.txt", "valid.txt", "test.txt")
+
+    def _cached_ids(self, task_dir, cache_dir):
+        """Parse the text files once; later runs load `<cache_dir>/<name>_ids.npz` while it is newer than every text file."""
+        os.makedirs(cache_dir, exist_ok=True)
+        path = os.path.join(cache_dir, os.path.basename(os.path.normpath(task_dir)) + "_ids.npz")
+        newest = max(os.path.getmtime(os.path.join(task_dir, f)) for f in self._FILES)
+        if os.path.exists(path) and os.path.getmtime(path) >= newest:
+            return dict(np.load(path))
+        self._read_text(task_dir)
+        ids = dict(n_ent=np.int64(self.n_ent), n_rel=np.int64(self.n_rel), facts=self.fact_triple, train=self.train_triple,
+                   valid=self.valid_triple, test=self.test_triple)
+        np.savez_compressed(path, **ids)
+        self.filters = defaultdict(set)                     # rebuilt from the ids below
+        return ids
 
     # ---- parsing (load_data.py:11-25, 58-67) ----------------------------------------------------
     def _read_text(self, task_dir):
@@ -157,17 +175,33 @@ class DataLoader:
             objs[i][answer[q]] = 1
         return subs, rels, objs
 
+    def _split_csr(self, data):
+        """Answers and filter sets of a whole split as device CSR lists, built once."""
+        cache = self.__dict__.setdefault("_csr_cache", {})
+        if data not in cache:
+            query, answer = (self.valid_q, self.valid_a) if data == "valid" else (self.test_q, self.test_a)
+            ans = [np.sort(np.asarray(a)) for a in answer]                # np.nonzero order of utils.py:12-13
+            fil = [np.asarray(self.filters[(int(s), int(r))]) for s, r in query]
+            ptr = lambda lists: np.concatenate([[0], np.cumsum([len(x) for x in lists])]).astype(np.int64)
+            cat = lambda lists: np.concatenate(lists) if len(lists) else np.zeros(0, np.int64)
+            to_dev = lambda a, dt: torch.as_tensor(np.asarray(a), dtype=dt).to(self.device)
+            cache[data] = (np.array([q[0] for q in query]), np.array([q[1] for q in query]), ptr(ans), to_dev(cat(ans), torch.int32),
+                           ptr(fil), to_dev(cat(fil), torch.int32))
+        return cache[data]
+
     def get_batch_csr(self, batch_idx, data="valid"):
-        """The same batch as device CSR lists for the GPU ranker: (subs, rels, ans_ptr, ans_idx, filt_ptr, filt_idx)."""
-        query, answer = (self.valid_q, self.valid_a) if data == "valid" else (self.test_q, self.test_a)
-        subs = np.array([query[i][0] for i in batch_idx])
-        rels = np.array([query[i][1] for i in batch_idx])
-        ans = [np.sort(np.asarray(answer[i])) for i in batch_idx]       # np.nonzero order of base_model.py / utils.py:12-13
-        fil = [np.asarray(self.filters[(int(s), int(r))]) for s, r in zip(subs, rels)]
+        """The same batch as device CSR lists for the GPU ranker: (subs, rels, ans_ptr, ans_idx, filt_ptr, filt_idx).
+        batch_idx must be a contiguous range (as the evaluator's batches are) or any index array."""
+        subs_all, rels_all, aptr, aidx, fptr, fidx = self._split_csr(data)
+        batch_idx = np.asarray(batch_idx)
         to_dev = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.int32).to(self.device)
-        ptr = lambda lists: np.concatenate([[0], np.cumsum([len(x) for x in lists])])
-        cat = lambda lists: np.concatenate(lists) if len(lists) else np.zeros(0, np.int64)
-        return subs, rels, to_dev(ptr(ans)), to_dev(cat(ans)), to_dev(ptr(fil)), to_dev(cat(fil))
+        if len(batch_idx) and np.array_equal(batch_idx, np.arange(batch_idx[0], batch_idx[0] + len(batch_idx))):
+            lo, hi = int(batch_idx[0]), int(batch_idx[-1]) + 1
+            return (subs_all[lo:hi], rels_all[lo:hi], to_dev(aptr[lo:hi + 1] - aptr[lo]), aidx[aptr[lo]:aptr[hi]],
+                    to_dev(fptr[lo:hi + 1] - fptr[lo]), fidx[fptr[lo]:fptr[hi]])
+        seg = lambda ptr, idx: torch.cat([idx[ptr[i]:ptr[i + 1]] for i in batch_idx]) if len(batch_idx) else idx[:0]
+        lens = lambda ptr: np.concatenate([[0], np.cumsum([ptr[i + 1] - ptr[i] for i in batch_idx])])
+        return subs_all[batch_idx], rels_all[batch_idx], to_dev(lens(aptr)), seg(aptr, aidx), to_dev(lens(fptr)), seg(fptr, fidx)
 
     def shuffle_train(self):
         """load_data.py:152-164: re-split facts/train 3:1 and rebuild the training graph."""

@@ -170,3 +170,20 @@ def test_bench_byte_model():
     import bench
     assert bench.algorithmic_bytes(10, 3, 64) == 10 * 272 + 3 * 256
     assert bench.algorithmic_bytes(1, 1, 128) == 528 + 512
+
+
+def test_loader_id_cache_roundtrip():
+    """Binary id cache of the parsed text: second construction reads the cache, same loader state."""
+    from red_gnn_amd.load_data import DataLoader
+    from red_gnn_amd.synthetic import make_synthetic_kg, write_task_dir
+    kg = make_synthetic_kg(40, 3, 200, seed=2)
+    with tempfile.TemporaryDirectory() as td:
+        task = os.path.join(td, "toy")
+        write_task_dir(kg, task)
+        a = DataLoader(task, verbose=False, cache_dir=os.path.join(td, "cache"))
+        assert os.path.exists(os.path.join(td, "cache", "toy_ids.npz"))
+        b = DataLoader(task, verbose=False, cache_dir=os.path.join(td, "cache"))
+        c = DataLoader(task, verbose=False)
+    for x in (a, b):
+        assert x.filters == c.filters and x.valid_q == c.valid_q and x.test_q == c.test_q
+        assert np.array_equal(x.fact_triple, c.fact_triple) and np.array_equal(x.train_data, c.train_data)
