@@ -536,3 +536,29 @@ def test_random_graphs_fuzz_vs_oracle():
             assert x["n_edges"] == len(y["edges"]), case
         np.testing.assert_allclose(s, ref, rtol=RTOL, atol=ATOL_H, err_msg="case %d" % case)
         assert np.array_equal(s == 0, ref == 0), case
+
+
+def test_inductive_training_learns():
+    """The reference's loop in the inductive setting (train on the transductive graph's valid triples, evaluate the
+    'test' split on the inductive graph with its own entity set): one short epoch lifts the inductive MRR."""
+    from red_gnn_amd.base_model import BaseModel
+    from red_gnn_amd.inductive import DataLoader
+    from red_gnn_amd.models import RED_GNN_induc
+    ids = U.load("ind_WN18RR_v1_ids.npz")
+    loader = DataLoader(ids=ids, verbose=False)
+
+    class Opt:      # Static/inductive/train.py WN18RR_v1 preset
+        lr, decay_rate, lamb, hidden_dim, attn_dim, n_layer, dropout, act, n_batch, n_tbatch = 0.005, 0.991, 0.0002, 64, 5, 5, 0.21, "relu", 100, 100
+        n_rel = loader.n_rel
+
+    np.random.seed(1234)
+    torch.manual_seed(1234)
+    bm = BaseModel(Opt, loader)
+    assert isinstance(bm.model, RED_GNN_induc)
+    bm.model.eval()
+    from red_gnn_amd.utils import cal_performance
+    mrr0 = cal_performance(bm._rank_split("test", bm.n_test))[0]
+    for epoch in range(3):
+        v_mrr, out = bm.train_batch(epoch=epoch)
+    t_mrr = float(out.split("[TEST] MRR:")[1].split()[0])
+    assert np.isfinite(bm.last_epoch_loss) and t_mrr > max(0.3, 2 * mrr0), (mrr0, out)
