@@ -26,6 +26,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12      # B/s, /opt/skills/guides/MI355X_MICROARCH.md (spec; ~6.3e12 achievable)
+MFMA_F32_PEAK = 157.3e12   # FLOP/s, same guide: f32-input MFMA = the FP32 vector rate
 
 
 class Params:
@@ -116,9 +117,10 @@ def main():
     q_idx = np.arange(lo, hi) % n_q
     subs, rels, a_ptr, a_idx, f_ptr, f_idx = loader.get_batch_csr(q_idx, data="test")
 
-    kernel_events = []
+    kernel_events, dense_events = [], []
     if not args.no_kernel_events:
         engine.KERNEL_EVENTS = kernel_events
+        engine.DENSE_EVENTS = dense_events
 
     pending = []     # the previous step's all-gather (RCCL stream): it overlaps the next step's kernels
 
@@ -139,6 +141,7 @@ def main():
     for _ in range(args.warmup):
         step()
     kernel_events.clear()
+    dense_events.clear()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -178,6 +181,16 @@ def main():
                         frac=achieved / HBM_PEAK, traffic=traffic, launches=n_launch,
                         avg_launch_ms=k_ms / n_launch, algorithmic_bytes_per_launch=k_bytes / n_launch,
                         kernel_edges_per_s=k_edges / (k_ms * 1e-3))
+        roof_dense = None
+        if dense_events:
+            # second kernel of the step: W_h + GRU + projections on f32 MFMA.  Algorithmic flops per node (what the
+            # reference computes): 2*d*d*(1 + 3 + 3) for W_h, weight_ih, weight_hh, + 2*d*attn_dim for the hoisted Ws_attn
+            d_ms = sum(e0.elapsed_time(e1) for (e0, e1, _) in dense_events)
+            rows = sum(n for (_, _, n) in dense_events)
+            flops = rows * (2.0 * d * d * 7 + 2.0 * d * shape["attn_dim"])
+            roof_dense = dict(bound="mfma", kernel="dense_kernel", achieved=flops / (d_ms * 1e-3) / 1e12, peak=MFMA_F32_PEAK / 1e12,
+                              unit="TFLOP/s", frac=flops / (d_ms * 1e-3) / MFMA_F32_PEAK, traffic=None, launches=len(dense_events),
+                              avg_launch_ms=d_ms / len(dense_events), algorithmic_flops_per_launch=flops / len(dense_events))
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             query, answer = loader.test_q, loader.test_a
@@ -197,7 +210,7 @@ def main():
             "eval_queries_per_s": B * world * args.steps / dt,
             "edges_per_step": total_edges / args.steps,
             "mrr_of_random_init": float(s[0] / s[3]),
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "roofline_dense": roof_dense, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
     if dist is not None:

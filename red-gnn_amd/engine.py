@@ -11,8 +11,10 @@ import torch
 from . import _lib
 
 
-# bench.py sets this to a list to collect (start_event, end_event, n_edges, n_new) per rg_layer_fwd launch
+# bench.py sets these to lists to collect (start_event, end_event, n_edges, n_new) per rg_layer_fwd launch and
+# (start_event, end_event, n_rows) per rg_dense_fwd launch
 KERNEL_EVENTS = None
+DENSE_EVENTS = None
 
 
 def _require_gpu(device):
@@ -243,10 +245,17 @@ def dense_fwd(agg, hidden_prev, prev_idx, d, W_h, act, gate, Ws_next=None, attn_
     c = lambda t: None if t is None else t.detach().contiguous()
     W_h, w_ih, w_hh, b_ih, b_hh = c(W_h), c(gate.weight_ih_l0), c(gate.weight_hh_l0), c(gate.bias_ih_l0), c(gate.bias_hh_l0)
     Ws_next, W_final = c(Ws_next), c(W_final)
+    ev = None
+    if DENSE_EVENTS is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
     _lib.check(_lib.lib().rg_dense_fwd(n, d, ld, _lib.ptr(agg), _lib.ptr(hidden_prev), _lib.ptr(prev_idx), _lib.ptr(W_h),
                                        {"idd": 0, "relu": 1, "tanh": 2}[act], _lib.ptr(w_ih), _lib.ptr(w_hh), _lib.ptr(b_ih),
                                        _lib.ptr(b_hh), _lib.ptr(Ws_next), attn_dim, ap, _lib.ptr(a_s), _lib.ptr(W_final),
                                        _lib.ptr(nodes), n_ent, _lib.ptr(scores_all), _lib.ptr(hidden), _lib.stream_ptr()))
+    if ev is not None:
+        ev[1].record()
+        DENSE_EVENTS.append((ev[0], ev[1], n))
     return hidden, a_s
 
 
