@@ -155,7 +155,7 @@ def _random_model(loader, n_layer, d, a, act, seed=1234):
 
 
 @pytest.mark.parametrize("d,a,act,n_layer", [(16, 3, "idd", 2), (20, 5, "tanh", 3), (32, 5, "relu", 3), (48, 5, "relu", 3),
-                                            (64, 5, "relu", 3), (128, 10, "relu", 2), (30, 30, "tanh", 2)])
+                                            (64, 5, "relu", 3), (128, 10, "relu", 2), (30, 30, "tanh", 2), (256, 5, "relu", 2), (100, 12, "tanh", 2)])
 def test_forward_vs_oracle_dims(d, a, act, n_layer):
     """Every hidden/attention width the reference's presets use, incl. d % 4 != 0."""
     from red_gnn_amd.load_data import DataLoader
