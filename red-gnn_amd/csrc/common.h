@@ -75,6 +75,11 @@ struct rg_graph {
   uint32_t* in_pk = nullptr;
   uint32_t* out_pk = nullptr;   // same packing for the CSR-by-head: (rel << 20 | tail)
   rg_vrows in_vr, out_vr;
+  // CSR by relation (rows = relation ids): rel_ht[n_fact] = {head, tail}; its virtual rows carry the relation id in the
+  // entity field.  Used by the backward's relation-gradient pass (one partial row per 128 edges instead of per edge).
+  int32_t* rel_ptr = nullptr;
+  int2* rel_ht = nullptr;
+  rg_vrows rel_vr;
 };
 
 // Frontier state, all inside the caller's workspace.

@@ -230,6 +230,19 @@ static int build_graph(int32_t n_ent, int32_t n_rel, int32_t n_rela_rows, const 
     RG_HIP_G(hipMalloc(&g->out_pk, std::max<int64_t>(n_fact, 1) * sizeof(uint32_t)));
     RG_HIP_G(hipMemcpy(g->out_pk, pk.data(), n_fact * sizeof(uint32_t), hipMemcpyHostToDevice));
   }
+  {
+    std::vector<int32_t> rel_ptr(n_rela_rows + 1, 0);
+    for (int64_t i = 0; i < n_fact; ++i) rel_ptr[R[i] + 1]++;
+    for (int32_t r = 0; r < n_rela_rows; ++r) rel_ptr[r + 1] += rel_ptr[r];
+    std::vector<int2> rel_ht(n_fact);
+    std::vector<int32_t> pr(rel_ptr.begin(), rel_ptr.end() - 1);
+    for (int64_t i = 0; i < n_fact; ++i) rel_ht[pr[R[i]]++] = make_int2(H[i], T[i]);
+    RG_HIP_G(hipMalloc(&g->rel_ptr, (n_rela_rows + 1) * sizeof(int32_t)));
+    RG_HIP_G(hipMalloc(&g->rel_ht, std::max<int64_t>(n_fact, 1) * sizeof(int2)));
+    RG_HIP_G(hipMemcpy(g->rel_ptr, rel_ptr.data(), (n_rela_rows + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+    RG_HIP_G(hipMemcpy(g->rel_ht, rel_ht.data(), n_fact * sizeof(int2), hipMemcpyHostToDevice));
+    if (build_vrows(rel_ptr, n_rela_rows, &g->rel_vr)) return fail();
+  }
 #undef RG_HIP_G
   if (build_vrows(in_ptr, n_ent, &g->in_vr) || build_vrows(out_ptr, n_ent, &g->out_vr)) return fail();
   *out = g;
@@ -284,7 +297,9 @@ int rg_graph_destroy(rg_graph* g) {
   if (g->in_pk) (void)hipFree(g->in_pk);
   if (g->out_pk) (void)hipFree(g->out_pk);
   if (g->in_time) (void)hipFree(g->in_time);
-  for (rg_vrows* v : {&g->in_vr, &g->out_vr}) {
+  if (g->rel_ptr) (void)hipFree(g->rel_ptr);
+  if (g->rel_ht) (void)hipFree(g->rel_ht);
+  for (rg_vrows* v : {&g->in_vr, &g->out_vr, &g->rel_vr}) {
     if (v->rows) (void)hipFree(v->rows);
     if (v->split) (void)hipFree(v->split);
   }

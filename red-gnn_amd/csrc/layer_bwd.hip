@@ -45,7 +45,7 @@ struct BwdArgs {
   float* g_ar;            // [n_rela_rows][ap]
   float* g_w;
   float* g_b;
-  int diag;   // RG_BWD_DIAG (timing experiments only): bit 0 skips the dRel accumulation
+  int diag;   // RG_BWD_DIAG (timing experiments only): bit 0 skips dRel entirely, bit 1 uses the in-kernel dRel path
 };
 
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -74,7 +74,9 @@ __device__ __forceinline__ float group_sum(float v) {
 
 constexpr int BWD_BLOCK = 512;
 
-template <int G, int AP4, bool PACKED, bool DENSE, bool RELA_LDS>
+// DREL: accumulate dRel inside this kernel (run-length + LDS atomics).  When false the separate relation-major pass
+// (drel_kernel below) computes it and this kernel only needs rela rows for the attention gradient's dot product.
+template <int G, int AP4, bool PACKED, bool DENSE, bool RELA_LDS, bool DREL>
 __global__ __launch_bounds__(BWD_BLOCK, 4) void layer_bwd_kernel(BwdArgs A) {
   extern __shared__ float4 lds[];
   constexpr int BLOCK = BWD_BLOCK;
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(BWD_BLOCK, 4) void layer_bwd_kernel(BwdArgs A) {
   // consecutive banks and four groups working on four different relations do not collide (ds_add_f32, 32 banks)
   constexpr int RS = 4 * G + 8;
   float* grela_l = reinterpret_cast<float*>(rela_l + (RELA_LDS ? nr * G : 0));   // [nr][RS]  (RELA_LDS)
-  int4* recs = reinterpret_cast<int4*>(grela_l + (RELA_LDS ? ((nr * RS + 3) & ~3) : 0));   // [BLOCK] (SPARSE only)
+  int4* recs = reinterpret_cast<int4*>(grela_l + ((RELA_LDS && DREL) ? ((nr * RS + 3) & ~3) : 0));   // [BLOCK] (SPARSE only)
 
   for (int i = threadIdx.x; i < nr * AP4; i += BLOCK) { ar_l[i] = A.a_r[i]; gar_l[i] = f4zero(); }
   if (threadIdx.x < AP4) {
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(BWD_BLOCK, 4) void layer_bwd_kernel(BwdArgs A) {
       const int r = i / G, c = i - r * G;
       rela_l[i] = c < A.ld4 ? A.rela[(int64_t)r * A.ld4 + c] : f4zero();
     }
-    for (int i = threadIdx.x; i < nr * RS; i += BLOCK) grela_l[i] = 0.f;
+    if constexpr (DREL) { for (int i = threadIdx.x; i < nr * RS; i += BLOCK) grela_l[i] = 0.f; }
   }
   __syncthreads();
   const float b_alpha = A.b_alpha[0];
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(BWD_BLOCK, 4) void layer_bwd_kernel(BwdArgs A) {
     int run_r = -1;
     float4 racc = f4zero();
     auto flush_run = [&]() {
-      if (run_r >= 0 && row_lane && !(A.diag & 1)) {
+      if (DREL && run_r >= 0 && row_lane && !(A.diag & 1)) {
         if constexpr (RELA_LDS) {
           float* gr = grela_l + run_r * RS + lane_g;
           atomicAdd(gr, racc.x); atomicAdd(gr + G, racc.y); atomicAdd(gr + 2 * G, racc.z); atomicAdd(gr + 3 * G, racc.w);
@@ -211,9 +213,11 @@ __global__ __launch_bounds__(BWD_BLOCK, 4) void layer_bwd_kernel(BwdArgs A) {
           if (lane_g == 0) reinterpret_cast<float*>(&my_stage[k + u])[3] = dot;
           const float4 ag = make_float4(al * gv[u].x, al * gv[u].y, al * gv[u].z, al * gv[u].w);
           acc.x += ag.x; acc.y += ag.y; acc.z += ag.z; acc.w += ag.w;
-          if (al != 0.f) {
-            if (ru != run_r) { flush_run(); run_r = ru; racc = f4zero(); }
-            racc.x += ag.x; racc.y += ag.y; racc.z += ag.z; racc.w += ag.w;
+          if constexpr (DREL) {
+            if (al != 0.f) {
+              if (ru != run_r) { flush_run(); run_r = ru; racc = f4zero(); }
+              racc.x += ag.x; racc.y += ag.y; racc.z += ag.z; racc.w += ag.w;
+            }
           }
         }
       }
@@ -270,7 +274,7 @@ __global__ __launch_bounds__(BWD_BLOCK, 4) void layer_bwd_kernel(BwdArgs A) {
     const float v = reinterpret_cast<float*>(gar_l)[i];
     if (v != 0.f) atomicAdd(A.g_ar + i, v);
   }
-  if constexpr (RELA_LDS) {
+  if constexpr (RELA_LDS && DREL) {
     for (int i = threadIdx.x; i < nr * A.ld4 * 4; i += BLOCK) {
       const int r = i / (A.ld4 * 4), c = i - r * (A.ld4 * 4);
       const float v = grela_l[r * RS + (c & 3) * G + (c >> 2)];
@@ -295,6 +299,165 @@ __global__ __launch_bounds__(BWD_BLOCK, 4) void layer_bwd_kernel(BwdArgs A) {
     for (int w = 0; w < BLOCK / 64; ++w) v += red[w * (AP4 * 4 + 4) + threadIdx.x];
     if (threadIdx.x == AP4 * 4) { if (v != 0.f) atomicAdd(A.g_b, v); }
     else if ((int)threadIdx.x < A.attn_dim && v != 0.f) atomicAdd(A.g_w + threadIdx.x, v);
+  }
+}
+
+
+// ---- relation gradient, relation-major --------------------------------------------------------------------------
+// dRel[r] = sum over queries b and KG edges (h, r, t) with (b,h) in the previous frontier of alpha * G[(b,t)].
+// Items are (query, 128-edge segment of relation r's edge list): the segment's sum is built in registers exactly as
+// the forward kernel builds a destination row (test + rank + attention per candidate lane, then row gathers of G), and
+// added to the workgroup's LDS copy of dRel ONCE per segment - 1/128th of the LDS float atomics of the per-edge form,
+// which were two thirds of the backward kernel's time.
+struct DrelArgs {
+  rg::WalkArgs walk;          // vrows = CSR-by-relation segments; always live
+  const int2* rel_ht;
+  const int2* bm_old;
+  const int2* bm_new;
+  int W;
+  const float4* a_s;
+  const float4* a_r;
+  const float4* a_q;
+  const float* w_alpha;
+  const float* b_alpha;
+  int attn_dim;
+  int n_rela_rows;
+  int ld4;
+  const float4* grad_agg;
+  float* g_rela;
+};
+
+template <int G, int AP4>
+__global__ __launch_bounds__(BWD_BLOCK, 4) void drel_kernel(DrelArgs A) {
+  extern __shared__ float4 lds[];
+  constexpr int BLOCK = BWD_BLOCK;
+  constexpr int RS = 4 * G + 8;
+  const int nr = A.n_rela_rows;
+  float4* stage = lds;                                   // [BLOCK] {o, alpha}
+  float4* ar_l = stage + BLOCK;                          // [nr][AP4]
+  float4* w_l = ar_l + nr * AP4;                         // [AP4]
+  float* grela_l = reinterpret_cast<float*>(w_l + AP4);  // [nr][RS]
+  for (int i = threadIdx.x; i < nr * AP4; i += BLOCK) ar_l[i] = A.a_r[i];
+  if (threadIdx.x < AP4) {
+    float w[4];
+    for (int k = 0; k < 4; ++k) {
+      const int j = threadIdx.x * 4 + k;
+      w[k] = j < A.attn_dim ? A.w_alpha[j] : 0.f;
+    }
+    w_l[threadIdx.x] = make_float4(w[0], w[1], w[2], w[3]);
+  }
+  for (int i = threadIdx.x; i < nr * RS; i += BLOCK) grela_l[i] = 0.f;
+  __syncthreads();
+  const float b_alpha = A.b_alpha[0];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lane_g = lane & (G - 1), gi_w = lane / G;
+  float4* my_stage = stage + wv * 64 + gi_w * G;
+  const int gshift = lane & ~(G - 1);
+  const unsigned long long gmask = G == 64 ? ~0ull : ((1ull << G) - 1ull);
+  const bool row_lane = lane_g < A.ld4;
+  const int lane_c = row_lane ? lane_g : A.ld4 - 1;
+
+  rg::walk_items<G, true, 1, BLOCK, true>(A.walk, nullptr, [&](const int4& R, bool live) {
+    const int beg = R.x, end = R.x + rg::walk_len(R), b = R.z, r = R.w;
+    const int2* old_row = A.bm_old + (int64_t)b * A.W;
+    const int2* new_row = A.bm_new + (int64_t)b * A.W;
+    float4 base[AP4];
+#pragma unroll
+    for (int k = 0; k < AP4; ++k) {
+      const float4 ar = ar_l[(live ? r : 0) * AP4 + k];
+      const float4 aq = A.a_q[(int64_t)b * AP4 + k];
+      base[k] = make_float4(ar.x + aq.x, ar.y + aq.y, ar.z + aq.z, ar.w + aq.w);
+    }
+    float4 acc = f4zero();
+    bool any = false;
+    for (int c0 = beg; c0 < end; c0 += G) {
+      const int c = c0 + lane_g;
+      bool valid = c < end;
+      int o = 0;
+      float alpha = 0.f;
+      if (valid) {
+        const int2 ht = A.rel_ht[c];
+        const int2 wp = old_row[ht.x >> 5];
+        const uint32_t word = (uint32_t)wp.x, bit = ht.x & 31;
+        valid = (word >> bit) & 1u;
+        if (valid) {
+          const int s = wp.y + __popc(word & ((1u << bit) - 1u));
+          const int2 wn = new_row[ht.y >> 5];
+          o = wn.y + __popc((uint32_t)wn.x & ((1u << (ht.y & 31)) - 1u));
+          float z = b_alpha;
+#pragma unroll
+          for (int k = 0; k < AP4; ++k) {
+            const float4 as = A.a_s[(int64_t)s * AP4 + k];
+            const float4 w = w_l[k];
+            z = fmaf(w.x, fmaxf(as.x + base[k].x, 0.f), z);
+            z = fmaf(w.y, fmaxf(as.y + base[k].y, 0.f), z);
+            z = fmaf(w.z, fmaxf(as.z + base[k].z, 0.f), z);
+            z = fmaf(w.w, fmaxf(as.w + base[k].w, 0.f), z);
+          }
+          alpha = __builtin_amdgcn_rcpf(1.0f + __expf(-z));
+        }
+      }
+      const unsigned long long m = (__ballot(valid) >> gshift) & gmask;
+      const int cnt = __popcll(m);
+      const int pos = __popcll(m & ((1ull << lane_g) - 1ull));
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      if (lane_g >= cnt) my_stage[lane_g] = f4zero();
+      if (valid) my_stage[pos] = make_float4(__int_as_float(o), alpha, 0.f, 0.f);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      any = any || cnt > 0;
+      for (int k = 0; k < cnt; k += 4) {
+        float4 tp[4], gv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) tp[u] = my_stage[k + u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) gv[u] = A.grad_agg[(int64_t)__float_as_int(tp[u].x) * A.ld4 + lane_c];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float al = tp[u].y;
+          acc.x = fmaf(al, gv[u].x, acc.x);
+          acc.y = fmaf(al, gv[u].y, acc.y);
+          acc.z = fmaf(al, gv[u].z, acc.z);
+          acc.w = fmaf(al, gv[u].w, acc.w);
+        }
+      }
+    }
+    if (live && any && row_lane) {
+      float* gr = grela_l + r * RS + lane_g;
+      atomicAdd(gr, acc.x); atomicAdd(gr + G, acc.y); atomicAdd(gr + 2 * G, acc.z); atomicAdd(gr + 3 * G, acc.w);
+    }
+  });
+
+  __syncthreads();
+  for (int i = threadIdx.x; i < nr * A.ld4 * 4; i += BLOCK) {
+    const int r = i / (A.ld4 * 4), c = i - r * (A.ld4 * 4);
+    const float v = grela_l[r * RS + (c & 3) * G + (c >> 2)];
+    if (v != 0.f) atomicAdd(A.g_rela + i, v);
+  }
+}
+
+template <int G, int AP4>
+int launch_drel(const DrelArgs& A, hipStream_t s) {
+  const size_t lds = (size_t)(BWD_BLOCK + A.n_rela_rows * AP4 + AP4) * sizeof(float4) + (size_t)A.n_rela_rows * (4 * G + 8) * sizeof(float);
+  auto kern = drel_kernel<G, AP4>;
+  if (lds > 64 * 1024) RG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int grid = rg::walk_grid(A.walk.n_items, BWD_BLOCK, G, true, lds <= 80 * 1024 ? 2 : 1, 1);
+  RG_HIP(hipMemsetAsync(A.walk.queues, 0, 8 * sizeof(int32_t), s));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(BWD_BLOCK), lds, s, A);
+  RG_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int G>
+int launch_drel_ap(const DrelArgs& A, int ap4, hipStream_t s) {
+  switch (ap4) {
+    case 1: return launch_drel<G, 1>(A, s);
+    case 2: return launch_drel<G, 2>(A, s);
+    case 3: return launch_drel<G, 3>(A, s);
+    case 4: return launch_drel<G, 4>(A, s);
+    case 8: return launch_drel<G, 8>(A, s);
+    default: rg::set_error("rg_layer_bwd: padded attention dim %d not in {4,8,12,16,32}", ap4 * 4); return 1;
   }
 }
 
@@ -325,9 +488,9 @@ __global__ void bwd_combine_kernel(const int4* __restrict__ split, int n_split, 
   else g_as[(int64_t)s * ap4 + (c - ld4)] = acc;
 }
 
-template <int G, int AP4, bool PACKED, bool DENSE, bool RELA_LDS>
+template <int G, int AP4, bool PACKED, bool DENSE, bool RELA_LDS, bool DREL>
 int launch3(const BwdArgs& A, size_t lds, int B, const rg_vrows& vr, const int2* bm_old, hipStream_t s) {
-  auto kern = layer_bwd_kernel<G, AP4, PACKED, DENSE, RELA_LDS>;
+  auto kern = layer_bwd_kernel<G, AP4, PACKED, DENSE, RELA_LDS, DREL>;
   if (lds > 64 * 1024) RG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int per_cu = lds <= 80 * 1024 ? 2 : 1;
   const int grid = rg::walk_grid(A.walk.n_items, BWD_BLOCK, G, DENSE, per_cu, 1);
@@ -349,8 +512,14 @@ int launch2(const BwdArgs& A, int B, const rg_vrows& vr, const int2* bm_old, hip
   if (!DENSE) lds += (size_t)BWD_BLOCK * sizeof(int4);
   const size_t rela_bytes = (size_t)A.n_rela_rows * G * sizeof(float4) + (((size_t)A.n_rela_rows * (4 * G + 8) + 3) & ~(size_t)3) * sizeof(float);
   RG_CHECK(lds <= 160 * 1024, "rg_layer_bwd: attention tables need %zu B of LDS (> 160 KiB)", lds);
-  if (lds + rela_bytes <= 80 * 1024) return launch3<G, AP4, PACKED, DENSE, true>(A, lds + rela_bytes, B, vr, bm_old, s);
-  return launch3<G, AP4, PACKED, DENSE, false>(A, lds, B, vr, bm_old, s);
+  const size_t rela_only = (size_t)A.n_rela_rows * G * sizeof(float4);
+  if (A.diag & 2) {   // in-kernel dRel (run-length LDS / global atomics): relation table too big for the separate pass, or RG_BWD_DIAG bit 1
+    if (lds + rela_bytes <= 80 * 1024) return launch3<G, AP4, PACKED, DENSE, true, true>(A, lds + rela_bytes, B, vr, bm_old, s);
+    return launch3<G, AP4, PACKED, DENSE, false, true>(A, lds, B, vr, bm_old, s);
+  }
+  // dRel comes from the relation-major pass (drel_kernel); here the rela rows are only read
+  if (lds + rela_only <= 80 * 1024) return launch3<G, AP4, PACKED, DENSE, true, false>(A, lds + rela_only + 64, B, vr, bm_old, s);
+  return launch3<G, AP4, PACKED, DENSE, false, false>(A, lds, B, vr, bm_old, s);
 }
 
 template <int G, int AP4>
@@ -421,9 +590,29 @@ extern "C" int rg_layer_bwd(const rg_frontier* f, const rg_graph* g, int32_t lev
   const bool dense = n_old >= 4 * (int64_t)f->B;
   const int ld4 = ld / 4;
   const int2* bm_old = f->bm_of(level - 1);
-  if (ld4 <= 4) return launch_ap<4>(A, ap / 4, f->B, g->out_vr, bm_old, dense, s);
-  if (ld4 <= 8) return launch_ap<8>(A, ap / 4, f->B, g->out_vr, bm_old, dense, s);
-  if (ld4 <= 16) return launch_ap<16>(A, ap / 4, f->B, g->out_vr, bm_old, dense, s);
-  if (ld4 <= 32) return launch_ap<32>(A, ap / 4, f->B, g->out_vr, bm_old, dense, s);
-  return launch_ap<64>(A, ap / 4, f->B, g->out_vr, bm_old, dense, s);
+  const int Gl = ld4 <= 4 ? 4 : ld4 <= 8 ? 8 : ld4 <= 16 ? 16 : ld4 <= 32 ? 32 : 64;
+  const size_t drel_lds = (size_t)(BWD_BLOCK + g->n_rela_rows * (ap / 4) + ap / 4) * sizeof(float4) +
+                          (size_t)g->n_rela_rows * (4 * Gl + 8) * sizeof(float);
+  if (drel_lds > 80 * 1024) A.diag |= 2;     // relation table too big for the relation-major pass: keep dRel in the main kernel
+  int rc;
+  if (ld4 <= 4) rc = launch_ap<4>(A, ap / 4, f->B, g->out_vr, bm_old, dense, s);
+  else if (ld4 <= 8) rc = launch_ap<8>(A, ap / 4, f->B, g->out_vr, bm_old, dense, s);
+  else if (ld4 <= 16) rc = launch_ap<16>(A, ap / 4, f->B, g->out_vr, bm_old, dense, s);
+  else if (ld4 <= 32) rc = launch_ap<32>(A, ap / 4, f->B, g->out_vr, bm_old, dense, s);
+  else rc = launch_ap<64>(A, ap / 4, f->B, g->out_vr, bm_old, dense, s);
+  if (rc || (A.diag & 3)) return rc;
+  // relation gradient, relation-major (see drel_kernel)
+  DrelArgs D;
+  D.walk.n_items = (int64_t)f->B * g->rel_vr.n; D.walk.n_vrows = g->rel_vr.n; D.walk.n_slots = 0; D.walk.vrows = g->rel_vr.rows;
+  D.walk.bm_test = nullptr; D.walk.W = f->W; D.walk.queues = f->counters + 16;
+  RG_CHECK(D.walk.n_items / 8 + ((int64_t)1 << 26) < ((int64_t)1 << 31), "rg_layer_bwd: relation work space too large for 32-bit queue tickets");
+  D.rel_ht = g->rel_ht; D.bm_old = bm_old; D.bm_new = f->bm_of(level); D.W = f->W;
+  D.a_s = (const float4*)a_s; D.a_r = (const float4*)a_r; D.a_q = (const float4*)a_q;
+  D.w_alpha = w_alpha; D.b_alpha = b_alpha; D.attn_dim = attn_dim; D.n_rela_rows = g->n_rela_rows; D.ld4 = ld4;
+  D.grad_agg = (const float4*)grad_agg; D.g_rela = grad_rela;
+  if (ld4 <= 4) return launch_drel_ap<4>(D, ap / 4, s);
+  if (ld4 <= 8) return launch_drel_ap<8>(D, ap / 4, s);
+  if (ld4 <= 16) return launch_drel_ap<16>(D, ap / 4, s);
+  if (ld4 <= 32) return launch_drel_ap<32>(D, ap / 4, s);
+  return launch_drel_ap<64>(D, ap / 4, s);
 }

@@ -39,7 +39,9 @@ __device__ __forceinline__ int walk_out(const int4& R, int n_slots) {
 }
 
 // run_item(const int4& R, bool live) is called by all 64 lanes of a wave with one item per group of G lanes.
-template <int G, bool DENSE, int KPG, int BLOCK, typename F>
+// ALWAYS: every item is live (rows that are not tied to an entity of the frontier, e.g. the CSR by relation); R.w is then
+// the row's own id (vrows[].x).
+template <int G, bool DENSE, int KPG, int BLOCK, bool ALWAYS = false, typename F = void>
 __device__ __forceinline__ void walk_items(const WalkArgs& A, int4* recs, F&& run_item) {
   constexpr int GW = 64 / G, WPB = BLOCK / 64;
   constexpr int STEP = DENSE ? WPB * GW * KPG : WPB * 64;
@@ -47,6 +49,7 @@ __device__ __forceinline__ void walk_items(const WalkArgs& A, int4* recs, F&& ru
 
   auto test_item = [&](int b, int vr, int4& rec) -> bool {
     const int4 row = A.vrows[vr];
+    if constexpr (ALWAYS) { rec = make_int4(row.y, row.z, b, row.x); return true; }
     const int2 wp = A.bm_test[(int64_t)b * A.W + (row.x >> 5)];
     const uint32_t word = (uint32_t)wp.x, bit = row.x & 31;
     if (!((word >> bit) & 1u)) return false;
