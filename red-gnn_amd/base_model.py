@@ -1,8 +1,11 @@
 """Trainer / evaluator with the reference's interface (Static/transductive/base_model.py:10-152).
 
-``BaseModel(args, loader)``, ``train_batch(epoch)``, ``evaluate(epoch)`` behave as the reference's;
-the evaluator ranks on the device (rg_rank) instead of copying [B, n_ent] scores to the host and
-sorting them twice per batch with scipy (base_model.py:106-118, utils.py:7-14).
+``BaseModel(args, loader)``, ``.train_batch(epoch)`` and ``.evaluate(epoch)`` behave as the reference's: Adam +
+ExponentialLR, the reference's (broadcast) loss, the NaN scrub after every step, filtered MRR / H@1 / H@10 over the
+valid and test splits, one ``loader.shuffle_train()`` per epoch.  What differs is where the work runs: scores never
+leave the device — ranking is ``rg_rank`` on CSR answer/filter lists instead of a host copy of ``[B, n_ent]`` scores and
+two scipy sorts per batch (base_model.py:106-118, utils.py:7-14) — and the NVML / RSS memory monitors of the reference
+(NVIDIA tooling) have no counterpart.
 """
 import time
 
@@ -14,77 +17,84 @@ from torch.optim.lr_scheduler import ExponentialLR
 from .models import RED_GNN_induc, RED_GNN_trans
 from .utils import cal_performance, cal_ranks_csr
 
+_OUT_FMT = ('[VALID] MRR:%.4f H@1:%.4f H@10:%.4f\t [TEST] MRR:%.4f H@1:%.4f H@10:%.4f '
+            '\t[TIME] train:%.4f inference:%.4f\n')
+
 
 def reference_loss(scores, tails):
     """base_model.py:58-60, literally: max_n keeps its [n,1] shape, so the sum runs over an
     [n,n] broadcast (= n x the per-query cross entropy).  Kept, because it scales every gradient."""
-    pos_scores = scores[torch.arange(len(scores), device=scores.device), tails]
-    max_n = torch.max(scores, 1, keepdim=True)[0]
-    return torch.sum(-pos_scores + max_n + torch.log(torch.sum(torch.exp(scores - max_n), 1)))
+    rows = torch.arange(scores.shape[0], device=scores.device)
+    row_max = scores.max(dim=1, keepdim=True).values                      # [n,1]
+    log_norm = torch.log(torch.exp(scores - row_max).sum(dim=1))         # [n]
+    return (row_max + log_norm - scores[rows, tails]).sum()              # [n,1] + [n] - [n] -> [n,n]
+
+
+def _chunks(n, size):
+    """Contiguous index ranges of at most `size` covering range(n)."""
+    return [np.arange(lo, min(lo + size, n)) for lo in range(0, n, size)]
 
 
 class BaseModel(object):
     def __init__(self, args, loader):
         # the inductive loader (two graphs) pairs with RED_GNN_induc (Static/inductive/base_model.py:14)
-        self.model = (RED_GNN_induc if getattr(loader, "inductive", False) else RED_GNN_trans)(args, loader)
-        self.model.cuda()
-        self.loader = loader
-        self.n_ent, self.n_rel = loader.n_ent, loader.n_rel
-        self.n_batch, self.n_tbatch = args.n_batch, args.n_tbatch
-        self.n_train, self.n_valid, self.n_test = loader.n_train, loader.n_valid, loader.n_test
-        self.n_layer = args.n_layer
-        self.args = args
+        net = RED_GNN_induc if getattr(loader, "inductive", False) else RED_GNN_trans
+        self.model = net(args, loader).cuda()
+        self.loader, self.args = loader, args
+        for name in ("n_ent", "n_rel", "n_train", "n_valid", "n_test"):
+            setattr(self, name, getattr(loader, name))
+        for name in ("n_batch", "n_tbatch", "n_layer"):
+            setattr(self, name, getattr(args, name))
         self.optimizer = Adam(self.model.parameters(), lr=args.lr, weight_decay=args.lamb)
         self.scheduler = ExponentialLR(self.optimizer, args.decay_rate)
         self.smooth = 1e-5
-        self.t_time = 0
+        self.t_time = 0.0
+        self.last_epoch_loss = float("nan")
 
+    # ---- one epoch of training followed by evaluation (base_model.py:32-83) ------------------------------------
     def train_batch(self, epoch=-1, max_batches=None):
-        epoch_loss = 0
-        batch_size = self.n_batch
-        n_batch = self.loader.n_train // batch_size + (self.loader.n_train % batch_size > 0)
-        if max_batches is not None:
-            n_batch = min(n_batch, max_batches)
-        t_time = time.time()
+        batches = _chunks(self.loader.n_train, self.n_batch)[:max_batches]
+        started = time.time()
         self.model.train()
-        for i in range(n_batch):
-            start, end = i * batch_size, min(self.loader.n_train, (i + 1) * batch_size)
-            triple = self.loader.get_batch(np.arange(start, end))
+        losses = []
+        for idx in batches:
+            triple = self.loader.get_batch(idx)
             self.model.zero_grad()
             scores = self.model(triple[:, 0], triple[:, 1])
-            loss = reference_loss(scores, torch.as_tensor(triple[:, 2], dtype=torch.long, device=scores.device))
+            tails = torch.as_tensor(triple[:, 2], dtype=torch.long, device=scores.device)
+            loss = reference_loss(scores, tails)
             loss.backward()
             self.optimizer.step()
-            # avoid NaN (base_model.py:64-69): one numpy draw per parameter, as the reference consumes them, but as a
-            # masked fill on the device (no host synchronisation per parameter)
-            for p in self.model.parameters():
-                p.data.masked_fill_(p.data != p.data, np.random.random())
-            epoch_loss += loss.item()
+            self._scrub_nan()
+            losses.append(loss.detach())
         self.scheduler.step()
-        self.t_time += time.time() - t_time
-        self.last_epoch_loss = epoch_loss
+        self.t_time += time.time() - started
+        self.last_epoch_loss = float(torch.stack(losses).sum()) if losses else 0.0
         valid_mrr, out_str = self.evaluate(epoch=epoch)
         self.loader.shuffle_train()
         return valid_mrr, out_str
 
+    def _scrub_nan(self):
+        """base_model.py:64-69: NaN parameters are replaced by a fresh numpy uniform draw — one draw per parameter
+        and step, as the reference consumes them, but as a masked fill on the device (no host synchronisation)."""
+        for p in self.model.parameters():
+            p.data.masked_fill_(torch.isnan(p.data), np.random.random())
+
+    # ---- filtered evaluation (base_model.py:85-152) ---------------------------------------------------------------
     def _rank_split(self, data, n_data):
-        batch_size = self.n_tbatch
-        n_batch = n_data // batch_size + (n_data % batch_size > 0)
-        ranking = []
-        for i in range(n_batch):
-            batch_idx = np.arange(i * batch_size, min(n_data, (i + 1) * batch_size))
-            subs, rels, ap, ai, fp, fi = self.loader.get_batch_csr(batch_idx, data=data)
-            with torch.no_grad():
-                scores = self.model(subs, rels, mode=self.loader.eval_mode(data) if hasattr(self.loader, "eval_mode") else data)
-                ranking.append(cal_ranks_csr(scores, ap, ai, fp, fi))
-        return torch.cat(ranking).double().cpu().numpy()
+        mode = self.loader.eval_mode(data) if hasattr(self.loader, "eval_mode") else data
+        ranks = []
+        with torch.no_grad():
+            for idx in _chunks(n_data, self.n_tbatch):
+                subs, rels, ans_ptr, ans_idx, filt_ptr, filt_idx = self.loader.get_batch_csr(idx, data=data)
+                scores = self.model(subs, rels, mode=mode)
+                ranks.append(cal_ranks_csr(scores, ans_ptr, ans_idx, filt_ptr, filt_idx))
+        return torch.cat(ranks).double().cpu().numpy()
 
     def evaluate(self, epoch=-1):
         self.model.eval()
-        i_time = time.time()
-        v_mrr, v_h1, v_h10 = cal_performance(self._rank_split("valid", self.n_valid))
-        t_mrr, t_h1, t_h10 = cal_performance(self._rank_split("test", self.n_test))
-        i_time = time.time() - i_time
-        out_str = '[VALID] MRR:%.4f H@1:%.4f H@10:%.4f\t [TEST] MRR:%.4f H@1:%.4f H@10:%.4f \t[TIME] train:%.4f inference:%.4f\n' % (
-            v_mrr, v_h1, v_h10, t_mrr, t_h1, t_h10, self.t_time, i_time)
-        return v_mrr, out_str
+        started = time.time()
+        valid = cal_performance(self._rank_split("valid", self.n_valid))
+        test = cal_performance(self._rank_split("test", self.n_test))
+        i_time = time.time() - started
+        return valid[0], _OUT_FMT % (*valid, *test, self.t_time, i_time)
