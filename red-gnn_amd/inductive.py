@@ -107,6 +107,8 @@ class DataLoader:
         key = (graph.n_ent, n_batch)
         fr = self._frontiers.get(key)
         if fr is None:
+            if len(self._frontiers) > 8:           # a handful of batch sizes is the norm; do not hoard workspaces
+                self._frontiers.clear()
             fr = self._frontiers[key] = Frontier(graph.n_ent, n_batch, 2, self.device)
         fr.reset_nodes(nodes_t)
         fr.expand(graph)
