@@ -62,6 +62,7 @@ struct rg_graph {
   int32_t n_rela_rows = 0;   // rows of the relation table: 2*n_rel+1 (static), n_rel_total+1 (temporal)
   int32_t n_time = 0;        // temporal graphs: number of time ids (0 = static graph)
   int32_t* in_time = nullptr;  // temporal graphs: time id of every CSR-by-tail entry
+  int32_t* out_time = nullptr; // ... and of every CSR-by-head entry (backward)
   int64_t n_fact = 0;
   int32_t max_in_deg = 0, max_out_deg = 0;
   // CSR by head: out_ptr[n_ent+1], out_rt[n_fact] = {rel, tail}

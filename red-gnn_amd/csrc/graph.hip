@@ -189,21 +189,27 @@ static int build_graph(int32_t n_ent, int32_t n_rel, int32_t n_rela_rows, const 
     in_ptr[e + 1] += in_ptr[e];
   }
   std::vector<int2> out_rt(n_fact), in_hr(n_fact);
-  std::vector<int32_t> in_time(TIME ? n_fact : 0);
+  std::vector<int32_t> in_time(TIME ? n_fact : 0), out_time(TIME ? n_fact : 0);
   {
     std::vector<int32_t> po(out_ptr.begin(), out_ptr.end() - 1), pi(in_ptr.begin(), in_ptr.end() - 1);
+    std::vector<int32_t> out_fact(n_fact);
     for (int64_t i = 0; i < n_fact; ++i) {  // stable: fact-row order inside each CSR row
-      out_rt[po[H[i]]++] = make_int2(R[i], T[i]);
+      out_fact[po[H[i]]++] = (int32_t)i;
       const int32_t q = pi[T[i]]++;
       in_hr[q] = make_int2(H[i], R[i]);
       if (TIME) in_time[q] = (*TIME)[i];
     }
+    // CSR-by-head rows ordered by relation (then fact order): the backward kernel then sees runs of equal relation
+    // and adds one partial sum per run (not per edge) to the privatised relation gradient
+    for (int32_t e = 0; e < n_ent; ++e)
+      std::stable_sort(out_fact.begin() + out_ptr[e], out_fact.begin() + out_ptr[e + 1],
+                       [&](int32_t a, int32_t b) { return R[a] < R[b]; });
+    for (int64_t j = 0; j < n_fact; ++j) {
+      const int32_t i = out_fact[j];
+      out_rt[j] = make_int2(R[i], T[i]);
+      if (TIME) out_time[j] = (*TIME)[i];
+    }
   }
-  // CSR-by-head rows ordered by relation: the backward kernel then sees runs of equal relation and adds one
-  // partial sum per run (not per edge) to the privatised relation gradient
-  for (int32_t e = 0; e < n_ent; ++e)
-    std::stable_sort(out_rt.begin() + out_ptr[e], out_rt.begin() + out_ptr[e + 1],
-                     [](const int2& a, const int2& b) { return a.x < b.x; });
   rg_graph* g = new rg_graph();
   g->n_ent = n_ent; g->n_rel = n_rel; g->n_rela_rows = n_rela_rows; g->n_time = n_time;
   g->n_fact = n_fact; g->max_in_deg = max_in; g->max_out_deg = max_out;
@@ -220,6 +226,8 @@ static int build_graph(int32_t n_ent, int32_t n_rel, int32_t n_rela_rows, const 
   if (TIME) {
     RG_HIP_G(hipMalloc(&g->in_time, std::max<int64_t>(n_fact, 1) * sizeof(int32_t)));
     RG_HIP_G(hipMemcpy(g->in_time, in_time.data(), n_fact * sizeof(int32_t), hipMemcpyHostToDevice));
+    RG_HIP_G(hipMalloc(&g->out_time, std::max<int64_t>(n_fact, 1) * sizeof(int32_t)));
+    RG_HIP_G(hipMemcpy(g->out_time, out_time.data(), n_fact * sizeof(int32_t), hipMemcpyHostToDevice));
   }
   if (n_ent <= (1 << 20) && n_rela_rows <= (1 << 12)) {
     std::vector<uint32_t> pk(n_fact);
@@ -297,6 +305,7 @@ int rg_graph_destroy(rg_graph* g) {
   if (g->in_pk) (void)hipFree(g->in_pk);
   if (g->out_pk) (void)hipFree(g->out_pk);
   if (g->in_time) (void)hipFree(g->in_time);
+  if (g->out_time) (void)hipFree(g->out_time);
   if (g->rel_ptr) (void)hipFree(g->rel_ptr);
   if (g->rel_ht) (void)hipFree(g->rel_ht);
   for (rg_vrows* v : {&g->in_vr, &g->out_vr, &g->rel_vr}) {

@@ -11,8 +11,10 @@ What is different inside: the per-call scipy coo build, the dense [B, n_ent] ind
 attention_vis loop with .item() syncs (model_cuda.py:121-135,163-166,178-184) do not exist; frontier expansion is the
 device bitmap walk, and the per-edge work of a layer is one fused kernel (rg_tlayer_fwd) with the three direction linears
 hoisted per node / relation / |dt| (W(h + r + tau) = Wh + Wr + Wtau).
-Scope (this round): forward in eval mode (`mode != 'train'`, i.e. no per-batch deletion of the query quadruples and
-dropout = identity); no backward kernel for the temporal variant yet.
+Training: ``mode='train'`` drops the batch's own quadruples (``batch['example_idx']`` rows of ``params.graph``,
+model_cuda.py:103-104) by building a device graph for the batch, applies ``nn.Dropout(params.dropout)`` before the
+activation (:196) and is differentiable: the per-edge work of the backward pass is rg_tlayer_bwd, the hoisted linears are
+ordinary autograd GEMMs.
 """
 import numpy as np
 import torch
@@ -24,6 +26,29 @@ from . import engine
 
 def _pad4(n):
     return (n + 3) // 4 * 4
+
+
+class _TAggregate(torch.autograd.Function):
+    """agg = rg_tlayer_fwd(...);  backward = rg_tlayer_bwd(...)."""
+
+    @staticmethod
+    def forward(ctx, hidden_dir, rela_dir, time_dir, a_s, a_r, a_q, w_alpha, b_alpha, frontier, graph, level, n_new, q_time,
+                batch_old, d, attn_dim):
+        hidden_dir, rela_dir, time_dir, a_s, a_r, a_q, w_alpha = (t.contiguous() for t in (hidden_dir, rela_dir, time_dir, a_s, a_r, a_q, w_alpha))
+        agg = engine.tlayer_fwd(frontier, graph, level, n_new, q_time, hidden_dir, rela_dir, time_dir, d, a_s, a_r, a_q,
+                                w_alpha, b_alpha, attn_dim)
+        ctx.save_for_backward(hidden_dir, rela_dir, time_dir, a_s, a_r, a_q, w_alpha, b_alpha, q_time, batch_old)
+        ctx.misc = (frontier, graph, level, d, attn_dim)
+        return agg
+
+    @staticmethod
+    def backward(ctx, grad_agg):
+        hidden_dir, rela_dir, time_dir, a_s, a_r, a_q, w_alpha, b_alpha, q_time, batch_old = ctx.saved_tensors
+        frontier, graph, level, d, attn_dim = ctx.misc
+        g_hd, g_rd, g_td, g_as, g_ar, g_w = engine.tlayer_bwd(frontier, graph, level, a_s.shape[0], q_time, hidden_dir, rela_dir,
+                                                              time_dir, d, a_s, a_r, a_q, w_alpha, b_alpha, attn_dim, grad_agg)
+        g_aq = torch.zeros_like(a_q).index_add_(0, batch_old, g_as)       # nodes are sorted by query
+        return (g_hd, g_rd, g_td, g_as, g_ar, g_aq, g_w.view_as(w_alpha)) + (None,) * 9
 
 
 class T_RED_GNN(nn.Module):
@@ -51,6 +76,8 @@ class T_RED_GNN(nn.Module):
         acts = {"tanh": torch.tanh, "sigmoid": torch.sigmoid, "relu": torch.relu, "idd": lambda x: x,
                 "softplus": F.softplus, "leaky_relu": F.leaky_relu}
         self.act = acts[params.act]
+        self.dropout = nn.Dropout(getattr(params, "dropout", 0.0))               # model_cuda.py:58
+        self.quads = np.ascontiguousarray(np.asarray(params.graph, dtype=np.int64).reshape(-1, 4))
         self.graph = engine.TemporalGraph(self.n_ent, self.n_rel + 1, self.n_time, params.graph,
                                           device=getattr(params, "device", "cuda"))
         self._frontiers = {}
@@ -61,44 +88,60 @@ class T_RED_GNN(nn.Module):
             return self.rela_embed.weight, self.attention_1.weight, self.attention_2.weight
         return self.rela_embed_layer[i].weight, self.attention_1_layer[i].weight, self.attention_2_layer[i].weight
 
-    @torch.no_grad()
-    def forward(self, batch, mode="test"):
-        if mode == "train":
-            raise NotImplementedError("the temporal variant runs inference only in this round (no per-batch fact deletion, "
-                                      "no backward kernel): SURVEY.md §8(f)")
+    def _frontier(self, n, n_levels, device):
+        key = (n, n_levels, str(device))
+        fr = self._frontiers.get(key)
+        if fr is None:
+            if len(self._frontiers) >= 8:
+                self._frontiers.clear()
+            fr = self._frontiers[key] = engine.Frontier(self.n_ent, n, n_levels, device)
+        return fr
+
+    def forward(self, batch, mode="train"):
         device = self.linear_classifier.weight.device
         engine._require_gpu(device)
         heads = torch.as_tensor(batch["head"]).to(device=device, dtype=torch.int32)
         q_rel = torch.as_tensor(batch["relation"]).to(device=device, dtype=torch.int64)
         q_time = torch.as_tensor(batch["time"]).to(device=device, dtype=torch.int32)
         n = heads.numel()
-        key = (n, str(device))
-        fr = self._frontiers.get(key)
-        if fr is None:
-            fr = self._frontiers[key] = engine.Frontier(self.n_ent, n, 2, device)
+        graph = self.graph
+        if mode == "train":     # model_cuda.py:103-104: the batch's own facts leave the graph
+            drop = np.asarray(torch.as_tensor(batch["example_idx"]).cpu()).reshape(-1)
+            graph = engine.TemporalGraph(self.n_ent, self.n_rel + 1, self.n_time, np.delete(self.quads, drop, axis=0), device=device)
+        with_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        fr = self._frontier(n, self.n_layer + 1 if with_grad else 2, device)
         fr.reset(heads)
         d, a = self.hidden_dim, self.attn_dim
         ld, ap = max(16, _pad4(d)), _pad4(a)
         w_dir = torch.cat([self.past_linear.weight, self.now_linear.weight, self.future_linear.weight], 0)     # [3d, d]
         padc = lambda t: F.pad(t, (0, ld - d)) if ld != d else t
+        pad_rows = lambda w: F.pad(w, (0, 0, 0, ap - a)) if ap != a else w
         time_dir = padc(F.linear(self.time_embed.weight, w_dir).view(self.n_time, 3, d).transpose(0, 1).reshape(3 * self.n_time, d)).contiguous()
         hidden = torch.zeros((n, d), device=device)
         zero_b = torch.zeros(1, device=device)
+        batch_old = torch.arange(n, device=device)
         n_edges, nodes = [], None
         for i in range(self.n_layer):
             rela, w1, w2 = self._tables(i)
-            n_new, n_e, n_old = fr.expand(self.graph)
+            n_new, n_e, n_old = fr.expand(graph)
             n_edges.append(n_e)
-            pad_rows = lambda w: F.pad(w, (0, 0, 0, ap - a)) if ap != a else w
             a_s = F.linear(hidden, pad_rows(w1[:, :d])).contiguous()                 # [n_old, ap]
             a_r = F.linear(rela, pad_rows(w1[:, d:2 * d])).contiguous()              # [n_rel+1, ap]
             a_q = F.linear(rela[q_rel], pad_rows(w1[:, 2 * d:])).contiguous()        # [B, ap]
             hidden_dir = padc(F.linear(hidden, w_dir).view(n_old * 3, d)).contiguous()          # row 3 s + dir
             rela_dir = padc(F.linear(rela, w_dir).view(-1, 3, d).transpose(0, 1).reshape(-1, d)).contiguous()   # row dir*(R+1) + r
-            agg = engine.tlayer_fwd(fr, self.graph, fr.level, n_new, q_time, hidden_dir, rela_dir, time_dir, d, a_s, a_r, a_q,
-                                    w2.reshape(-1).contiguous(), zero_b, a)
-            hidden = self.act(agg[:, :d])                                             # model_cuda.py:196 (dropout = identity in eval)
-        nodes, _, _ = fr.nodes(want_prev=False, want_old_new=False)
+            w_alpha = w2.reshape(-1).contiguous()
+            if with_grad:
+                agg = _TAggregate.apply(hidden_dir, rela_dir, time_dir, a_s, a_r, a_q, w_alpha, zero_b, fr, graph, fr.level, n_new,
+                                        q_time, batch_old, d, a)
+            else:
+                with torch.no_grad():
+                    agg = engine.tlayer_fwd(fr, graph, fr.level, n_new, q_time, hidden_dir, rela_dir, time_dir, d, a_s, a_r, a_q,
+                                            w_alpha, zero_b, a)
+            hidden = self.act(self.dropout(agg[:, :d]))                               # model_cuda.py:196
+            if with_grad or i == self.n_layer - 1:
+                nodes, _, _ = fr.nodes(want_prev=False, want_old_new=False)
+                batch_old = nodes[:, 0].long()
         result = self.linear_classifier(hidden).reshape(-1)                           # model_cuda.py:210
         key_idx = nodes[:, 0].long() * self.n_ent + nodes[:, 1].long()
         score_all = torch.zeros(n * self.n_ent, device=device).index_copy(0, key_idx, result)

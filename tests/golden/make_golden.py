@@ -301,6 +301,48 @@ def case_temporal(out_dir):
     np.savez_compressed(os.path.join(out_dir, "temporal_model_py.npz"), **rec)
 
 
+def case_temporal_train(out_dir):
+    """One training step's gradients from Temporal/interpolation/model.py + the loss of main.py:70-82: the batch's own
+    quadruples (example_idx) leave the graph (model.py:45), softmax + nll on the scores, parameter gradients recorded."""
+    import importlib.util
+    import torch.nn.functional as F
+    tdir = "/root/reference/Temporal/interpolation"
+    spec = importlib.util.spec_from_file_location("ref_temporal_model", os.path.join(tdir, "model.py"))
+    tm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tm)
+    rng = np.random.default_rng(12)
+    n_ent, n_rel, n_time, n_q = 50, 6, 365, 900
+    w = 1.0 / np.arange(1, n_ent + 1); w /= w.sum()
+    h, t = rng.choice(n_ent, n_q, p=w), rng.integers(0, n_ent, n_q)       # a few hub heads (rows longer than one 128-entry segment)
+    r, tau = rng.integers(0, n_rel - 1, n_q), rng.integers(0, n_time - 1, n_q)
+    tau[:60] = tau[60:120]
+    quads = np.stack([h, r, t, tau], 1)
+    idd = np.stack([np.arange(n_ent), np.full(n_ent, n_rel - 1), np.arange(n_ent), np.full(n_ent, n_time - 1)], 1)
+    graph = np.concatenate([quads, idd], 0).astype(np.int64)
+
+    class Prm:
+        relation_vocab, entity_vocab, device = list(range(n_rel)), list(range(n_ent)), "cpu"
+    Prm.graph = graph
+    np.random.seed(4321)
+    torch.manual_seed(4321)
+    model = tm.T_RED_GNN(Prm).train()
+    ex = np.array([3, 17, 60, 61, 200, 411, 555, 899])
+    batch = {"head": torch.as_tensor(quads[ex, 0]), "relation": torch.as_tensor(quads[ex, 1]), "time": torch.as_tensor(quads[ex, 3]),
+             "tail": torch.as_tensor(quads[ex, 2]), "example_idx": torch.as_tensor(ex)}
+    scores = model(batch)
+    loss = F.nll_loss(torch.log(F.softmax(scores, dim=1) + 1e-12), batch["tail"])
+    loss.backward()
+    rec = dict(quads=graph.astype(np.int32), n_ent=np.int64(n_ent), n_rel=np.int64(n_rel), n_time=np.int64(n_time),
+               heads=batch["head"].numpy().astype(np.int32), rels=batch["relation"].numpy().astype(np.int32),
+               times=batch["time"].numpy().astype(np.int32), tails=batch["tail"].numpy().astype(np.int64),
+               example_idx=ex.astype(np.int64), scores=scores.detach().numpy(), loss=np.float64(loss.item()),
+               cfg=np.array([3, 20, 30], dtype=np.int64), act=np.array("leaky_relu"))
+    for k, v in model.named_parameters():
+        rec["param::" + k] = v.detach().numpy()
+        rec["grad::" + k] = v.grad.numpy()
+    np.savez_compressed(os.path.join(out_dir, "temporal_model_py_train.npz"), **rec)
+
+
 def case_ranks(out_dir):
     rng = np.random.default_rng(5)
     n, m = 12, 300
@@ -326,6 +368,9 @@ def case_ranks(out_dir):
 
 if __name__ == "__main__":
     out = HERE
+    if sys.argv[1:] == ["temporal_train"]:      # regenerate only this case
+        case_temporal_train(out)
+        sys.exit(0)
     case_tiny(out)
     case_ranks(out)
     case_dataset(out, "family", 3, [48, 64], "relu", 8)
@@ -333,6 +378,7 @@ if __name__ == "__main__":
     case_dataset(out, "WN18RR", 5, [48], "tanh", 4, light=True)
     case_inductive(out)
     case_temporal(out)
+    case_temporal_train(out)
     for f in sorted(os.listdir(out)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(out, f)))

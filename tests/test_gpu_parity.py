@@ -10,6 +10,7 @@ rtol 2e-3 / atol 2e-5 on gradients (sums over every edge of the batch).
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from oracle import redgnn_oracle as orc
 from tests import _util as U
@@ -360,7 +361,7 @@ def test_temporal_matches_reference_model_py_fixture():
     n_layer, d, a = (int(x) for x in fx["cfg"])
     model = _temporal_model(fx, True, n_layer, d, a, str(fx["act"]))
     model.load_state_dict({k: torch.tensor(v) for k, v in U.params_of(fx).items()}, strict=True)
-    s = model({"head": fx["heads"], "relation": fx["rels"], "time": fx["times"]}, mode="test").cpu().numpy()
+    s = model({"head": fx["heads"], "relation": fx["rels"], "time": fx["times"]}, mode="test").detach().cpu().numpy()
     np.testing.assert_allclose(s, fx["scores"], rtol=RTOL, atol=ATOL)
     assert np.array_equal(s == 0, fx["scores"] == 0)
 
@@ -380,11 +381,69 @@ def test_temporal_per_layer_tables_vs_oracle(d, a, act, n_layer):
     model = _temporal_model(fx, False, n_layer, d, a, act, seed=9)
     B = 7
     batch = {"head": quads[:B, 0], "relation": quads[:B, 1], "time": quads[:B, 3]}
-    s = model(batch, mode="test").cpu().numpy()
+    with torch.no_grad():
+        s = model(batch, mode="test").cpu().numpy()
     p = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     ref = orc.temporal_forward(p, fx["quads"], n_ent, batch["head"], batch["relation"], batch["time"], n_layer, act).numpy()
     np.testing.assert_allclose(s, ref, rtol=RTOL, atol=ATOL_H)
     assert np.array_equal(s == 0, ref == 0)
+
+
+def _grads(model):
+    return {k: (v.grad.detach().cpu().numpy() if v.grad is not None else None) for k, v in model.named_parameters()}
+
+
+def test_temporal_train_step_matches_reference_model_py_fixture():
+    """A training step of T-RED-GNN (mode='train': the batch's quadruples leave the graph; rg_tlayer_fwd + rg_tlayer_bwd)
+    vs scores, loss and parameter gradients of the reference's model.py + main.py:70-82."""
+    fx = U.load("temporal_model_py_train.npz")
+    n_layer, d, a = (int(x) for x in fx["cfg"])
+    model = _temporal_model(fx, True, n_layer, d, a, str(fx["act"])).train()
+    model.load_state_dict({k: torch.tensor(v) for k, v in U.params_of(fx).items()}, strict=True)
+    batch = {"head": fx["heads"], "relation": fx["rels"], "time": fx["times"], "example_idx": fx["example_idx"]}
+    s = model(batch, mode="train")
+    np.testing.assert_allclose(s.detach().cpu().numpy(), fx["scores"], rtol=RTOL, atol=ATOL)
+    loss = F.nll_loss(torch.log(F.softmax(s, dim=1) + 1e-12), torch.tensor(fx["tails"], device="cuda"))
+    assert abs(loss.item() - float(fx["loss"])) < 1e-5
+    loss.backward()
+    for k, g in _grads(model).items():
+        ref = fx["grad::" + k]
+        np.testing.assert_allclose(g, ref, rtol=2e-4, atol=1e-5 * max(1.0, float(np.abs(ref).max())), err_msg=k)
+
+
+@pytest.mark.parametrize("d,a,act,n_layer,B", [(64, 30, "relu", 3, 7), (32, 5, "tanh", 3, 40), (20, 30, "idd", 2, 3), (128, 16, "tanh", 2, 5)])
+def test_temporal_backward_vs_oracle_autograd(d, a, act, n_layer, B):
+    """Per-layer tables (model_cuda.py layout), hub rows cut into segments, sparse and dense walks: parameter gradients of a
+    weighted score sum vs autograd through the oracle.  (The attention MLP's relu has a kink: an edge whose pre-activation
+    rounds to the other side of 0 in one of the two implementations shifts ONE row of attention_1's gradient by that edge's
+    term; the error message names the rows so such a flip is recognisable.  The seeds below have none.)"""
+    rng = np.random.default_rng(5)
+    n_ent, n_rel, n_time, n_q = 300, 9, 365, 4000
+    w = 1.0 / np.arange(1, n_ent + 1); w /= w.sum()
+    h, t = rng.choice(n_ent, n_q, p=w), rng.integers(0, n_ent, n_q)
+    quads = np.stack([h, rng.integers(0, n_rel - 1, n_q), t, rng.integers(0, n_time - 1, n_q)], 1)
+    quads[:100, 3] = quads[100:200, 3]
+    idd = np.stack([np.arange(n_ent), np.full(n_ent, n_rel - 1), np.arange(n_ent), np.full(n_ent, n_time - 1)], 1)
+    full = np.concatenate([quads, quads[:, [2, 1, 0, 3]], idd], 0).astype(np.int32)
+    fx = dict(quads=full, n_ent=n_ent, n_rel=n_rel, n_time=n_time)
+    model = _temporal_model(fx, False, n_layer, d, a, act, seed=11).train()
+    ex = rng.choice(n_q, B, replace=False)
+    batch = {"head": quads[ex, 0], "relation": quads[ex, 1], "time": quads[ex, 3], "example_idx": ex}
+    weight = torch.tensor(rng.standard_normal((B, n_ent)), dtype=torch.float32)
+    s = model(batch, mode="train")
+    (s * weight.cuda()).sum().backward()
+    p = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.named_parameters()}
+    ref = orc.temporal_forward(p, np.delete(full, ex, axis=0), n_ent, batch["head"], batch["relation"], batch["time"], n_layer, act)
+    np.testing.assert_allclose(s.detach().cpu().numpy(), ref.detach().numpy(), rtol=RTOL, atol=ATOL_H)
+    (ref * weight).sum().backward()
+    for k, g in _grads(model).items():
+        if p[k].grad is None:
+            assert g is None or not np.any(g), k          # score_embed_layer / query_relation_linear: unused by the forward
+            continue
+        r = p[k].grad.numpy()
+        atol = 2e-5 * max(1.0, float(np.abs(r).max()))
+        bad = np.argwhere(~np.isclose(g, r, rtol=2e-3, atol=atol))
+        np.testing.assert_allclose(g, r, rtol=2e-3, atol=atol, err_msg="%s rows %s cols %s" % (k, np.unique(bad[:, 0]), np.unique(bad[:, -1])))
 
 
 # ---- edge cases ------------------------------------------------------------------------------------------------

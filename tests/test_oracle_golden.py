@@ -125,3 +125,19 @@ def test_temporal_fixture_model_py():
                                    rtol=RTOL, atol=ATOL)
     np.testing.assert_allclose(s.numpy(), fx["scores"], rtol=RTOL, atol=ATOL)
     assert np.array_equal(s.numpy() == 0, fx["scores"] == 0)
+
+
+def test_temporal_train_fixture_model_py():
+    """One training step of model.py (batch facts deleted, main.py:70-82 loss): the oracle's scores, loss and parameter
+    gradients (autograd through the restatement) against the reference's."""
+    fx = U.load("temporal_model_py_train.npz")
+    p = {k: torch.tensor(v, requires_grad=True) for k, v in U.params_of(fx).items()}
+    quads = np.delete(fx["quads"], fx["example_idx"], axis=0)                  # model.py:45
+    s = orc.temporal_forward(p, quads, int(fx["n_ent"]), fx["heads"], fx["rels"], fx["times"], int(fx["cfg"][0]), str(fx["act"]),
+                             shared_tables=True)
+    np.testing.assert_allclose(s.detach().numpy(), fx["scores"], rtol=RTOL, atol=ATOL)
+    loss = torch.nn.functional.nll_loss(torch.log(torch.softmax(s, 1) + 1e-12), torch.tensor(fx["tails"]))
+    assert abs(loss.item() - float(fx["loss"])) < 1e-5
+    loss.backward()
+    for k, v in p.items():
+        np.testing.assert_allclose(v.grad.numpy(), fx["grad::" + k], rtol=1e-4, atol=2e-6, err_msg=k)
