@@ -10,8 +10,10 @@ What is different inside (nothing is different outside):
   * models.py:29-39 (gathers, attention, torch_scatter sum) is one fused kernel, rg_layer_fwd, and
     its adjoint rg_layer_bwd; the three attention Linear layers are hoisted to per-node /
     per-relation / per-query projections (exact re-association, SURVEY.md §9);
-  * dense algebra that is not on the E-proportional path (W_h, GRU cell, hoisted projections,
-    W_final) stays in torch on the device (rocBLAS / fused gru_cell), differentiable as usual.
+  * dense algebra that is not on the E-proportional path (W_h, GRU cell, hoisted projections, W_final): inference runs it
+    in one f32-MFMA kernel per layer (rg_dense_fwd); training keeps it in torch on the device, with the weight gradients
+    of the node-row GEMMs issued in row-chunked batched form (``tall_linear``: a [m,n] = G^T X product over millions of
+    rows otherwise lands on a handful of workgroups).
 """
 import numpy as np
 import torch
@@ -23,6 +25,54 @@ from . import engine
 
 def _pad4(n):
     return (n + 3) // 4 * 4
+
+
+_TALL_ROWS = 1 << 15        # below this a plain GEMM is as good
+_TALL_CHUNKS = 256          # ~ one row chunk per CU
+
+
+def _gram_tn(g, x):
+    """g^T x for g [N,m], x [N,n] with N >> m,n: chunks of rows as one batched GEMM, then a sum over the chunks
+    (fills the chip and shortens every fp32 accumulation chain by the chunk count)."""
+    n_rows = g.shape[0]
+    if n_rows < _TALL_ROWS:
+        return g.t() @ x
+    c = n_rows // _TALL_CHUNKS
+    body = _TALL_CHUNKS * c
+    out = torch.bmm(g[:body].view(_TALL_CHUNKS, c, -1).transpose(1, 2), x[:body].view(_TALL_CHUNKS, c, -1)).sum(0)
+    if body < n_rows:
+        out = out + g[body:].t() @ x[body:]
+    return out
+
+
+class _TallLinear(torch.autograd.Function):
+    """F.linear(x, weight, bias) for node-row matrices: same forward, weight gradient through _gram_tn."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g = g.contiguous()
+        gx = g @ weight if ctx.needs_input_grad[0] else None
+        gw = _gram_tn(g, x.contiguous()) if ctx.needs_input_grad[1] else None
+        gb = g.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return gx, gw, gb
+
+
+def tall_linear(x, weight, bias=None):
+    return _TallLinear.apply(x, weight, bias)
+
+
+def gru_step(x, h0, gate):
+    """Single-step nn.GRU (models.py:83) = torch.gru_cell, with the two gate GEMMs issued through tall_linear."""
+    gi = tall_linear(x, gate.weight_ih_l0)
+    gh = tall_linear(h0, gate.weight_hh_l0)
+    return torch.ops.aten._thnn_fused_gru_cell(gi, gh, h0, gate.bias_ih_l0, gate.bias_hh_l0)[0]
 
 
 class _Aggregate(torch.autograd.Function):
@@ -81,7 +131,7 @@ class GNNLayer(nn.Module):
         ld, ap = max(16, _pad4(d)), _pad4(a)
         rela = self.rela_embed.weight
         pad_rows = lambda w: F.pad(w, (0, 0, 0, ap - a)) if ap != a else w
-        a_s = F.linear(hidden, pad_rows(self.Ws_attn.weight))                                   # [n_old, ap]
+        a_s = tall_linear(hidden, pad_rows(self.Ws_attn.weight))                                # [n_old, ap]
         a_r = F.linear(rela, pad_rows(self.Wr_attn.weight))                                     # [2R+1, ap]
         a_q = F.linear(rela[q_rel], pad_rows(self.Wqr_attn.weight), F.pad(self.Wqr_attn.bias, (0, ap - a)))  # [B, ap]
         if ld != d:
@@ -91,7 +141,8 @@ class GNNLayer(nn.Module):
         return agg[:, :d] if ld != d else agg
 
     def forward(self, q_sub, q_rel, hidden, frontier, graph, level, nodes_new, nodes_old):
-        return self.act(self.W_h(self.aggregate(q_rel, hidden, frontier, graph, level, nodes_new, nodes_old)))   # models.py:41
+        agg = self.aggregate(q_rel, hidden, frontier, graph, level, nodes_new, nodes_old)
+        return self.act(tall_linear(agg, self.W_h.weight))                       # models.py:41
 
 
 class RED_GNN_trans(nn.Module):
@@ -147,12 +198,12 @@ class RED_GNN_trans(nn.Module):
             hidden = self.gnn_layers[i](q_sub, q_rel, hidden, fr, graph, fr.level, nodes, nodes_old)   # models.py:80
             h0 = torch.zeros((n_new, d), device=device).index_copy(0, old_new.long(), h0)           # models.py:81
             hidden = self.dropout(hidden)                                        # models.py:82
-            hidden = torch.gru_cell(hidden, h0, g.weight_ih_l0, g.weight_hh_l0, g.bias_ih_l0, g.bias_hh_l0)   # models.py:83
+            hidden = gru_step(hidden, h0, g)                                     # models.py:83
             h0 = hidden
             if trace is not None:
                 trace.append(dict(nodes=nodes, old_nodes_new_idx=old_new, n_edges=n_e, hidden=hidden))
             nodes_old = nodes
-        scores = self.W_final(hidden).squeeze(-1)                                # models.py:86
+        scores = tall_linear(hidden, self.W_final.weight).squeeze(-1)            # models.py:86
         key = nodes_old[:, 0].long() * n_ent + nodes_old[:, 1].long()
         scores_all = torch.zeros(n * n_ent, device=device).index_copy(0, key, scores)    # models.py:87-88
         self.last_stats = dict(n_edges=n_edges, n_nodes=int(nodes_old.shape[0]))

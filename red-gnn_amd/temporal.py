@@ -22,6 +22,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import engine
+from .models import tall_linear
 
 
 def _pad4(n):
@@ -125,10 +126,10 @@ class T_RED_GNN(nn.Module):
             rela, w1, w2 = self._tables(i)
             n_new, n_e, n_old = fr.expand(graph)
             n_edges.append(n_e)
-            a_s = F.linear(hidden, pad_rows(w1[:, :d])).contiguous()                 # [n_old, ap]
+            a_s = tall_linear(hidden, pad_rows(w1[:, :d])).contiguous()               # [n_old, ap]
             a_r = F.linear(rela, pad_rows(w1[:, d:2 * d])).contiguous()              # [n_rel+1, ap]
             a_q = F.linear(rela[q_rel], pad_rows(w1[:, 2 * d:])).contiguous()        # [B, ap]
-            hidden_dir = padc(F.linear(hidden, w_dir).view(n_old * 3, d)).contiguous()          # row 3 s + dir
+            hidden_dir = padc(tall_linear(hidden, w_dir).view(n_old * 3, d)).contiguous()        # row 3 s + dir
             rela_dir = padc(F.linear(rela, w_dir).view(-1, 3, d).transpose(0, 1).reshape(-1, d)).contiguous()   # row dir*(R+1) + r
             w_alpha = w2.reshape(-1).contiguous()
             if with_grad:
@@ -142,7 +143,7 @@ class T_RED_GNN(nn.Module):
             if with_grad or i == self.n_layer - 1:
                 nodes, _, _ = fr.nodes(want_prev=False, want_old_new=False)
                 batch_old = nodes[:, 0].long()
-        result = self.linear_classifier(hidden).reshape(-1)                           # model_cuda.py:210
+        result = tall_linear(hidden, self.linear_classifier.weight, self.linear_classifier.bias).reshape(-1)   # model_cuda.py:210
         key_idx = nodes[:, 0].long() * self.n_ent + nodes[:, 1].long()
         score_all = torch.zeros(n * self.n_ent, device=device).index_copy(0, key_idx, result)
         self.last_stats = dict(n_edges=n_edges, n_nodes=int(nodes.shape[0]))
