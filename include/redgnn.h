@@ -122,23 +122,24 @@ int rg_tlayer_fwd(const rg_frontier* f, const rg_graph* g, int32_t level, int64_
 /* ---- layer backward: adjoint of rg_layer_fwd (autograd of models.py:29-39) --------------------
  * grad_agg [N_new, ld].  grad_hidden [N_old, ld] and grad_a_s [N_old, ap] are WRITTEN (every row);
  * grad_rela [2R+1, ld], grad_a_r [2R+1, ap], grad_w_alpha [attn_dim], grad_b_alpha [1] are ACCUMULATED
- * into (caller zero-fills).  grad_a_q [B, ap] is the per-query segment sum of grad_a_s and is left to
- * the caller.  n_old is checked against the frontier.  scratch: rg_layer_bwd_scratch_bytes() bytes. */
+ * into (caller zero-fills).  grad_a_q [B, ap] (may be NULL) is WRITTEN: the per-query segment sum of grad_a_s
+ * (a_s[s] and a_q[b] enter the attention as a sum).  n_old is checked against the frontier.
+ * scratch: rg_layer_bwd_scratch_bytes() bytes. */
 size_t rg_layer_bwd_scratch_bytes(const rg_frontier* f, const rg_graph* g, int32_t ld, int32_t ap);
 int rg_layer_bwd(const rg_frontier* f, const rg_graph* g, int32_t level, int64_t n_old,
                  const float* hidden, const float* rela, int32_t d, int32_t ld,
                  const float* a_s, const float* a_r, const float* a_q, int32_t ap,
                  const float* w_alpha, const float* b_alpha, int32_t attn_dim,
                  const float* grad_agg,
-                 float* grad_hidden, float* grad_rela, float* grad_a_s, float* grad_a_r,
+                 float* grad_hidden, float* grad_rela, float* grad_a_s, float* grad_a_r, float* grad_a_q,
                  float* grad_w_alpha, float* grad_b_alpha,
                  void* scratch_dev, size_t scratch_bytes, void* stream);
 
 /* ---- temporal layer backward: adjoint of rg_tlayer_fwd (autograd of Temporal/interpolation/model_cuda.py:149-160,192) ----
  * Arguments as rg_tlayer_fwd.  grad_hidden_dir [N_old, 3*ld] (row s = the three direction rows 3s..3s+2) and
  * grad_a_s [N_old, ap] are WRITTEN (every row); grad_rela_dir [3*n_rela_rows, ld], grad_time_dir [3*n_time, ld],
- * grad_a_r [n_rela_rows, ap], grad_w_alpha [attn_dim] are ACCUMULATED into (caller zero-fills); grad_a_q is the
- * per-query segment sum of grad_a_s (caller).  The direction linears are differentiated by the caller
+ * grad_a_r [n_rela_rows, ap], grad_w_alpha [attn_dim] are ACCUMULATED into (caller zero-fills); grad_a_q [B, ap] (may
+ * be NULL) is WRITTEN, the per-query segment sum of grad_a_s.  The direction linears are differentiated by the caller
  * (three GEMMs on these sums).  Needs a graph from rg_tgraph_create. */
 size_t rg_tlayer_bwd_scratch_bytes(const rg_frontier* f, const rg_graph* g, int32_t ld, int32_t ap);
 int rg_tlayer_bwd(const rg_frontier* f, const rg_graph* g, int32_t level, int64_t n_old, const int32_t* q_time,
@@ -147,7 +148,7 @@ int rg_tlayer_bwd(const rg_frontier* f, const rg_graph* g, int32_t level, int64_
                   const float* w_alpha, const float* b_alpha, int32_t attn_dim,
                   const float* grad_agg,
                   float* grad_hidden_dir, float* grad_rela_dir, float* grad_time_dir, float* grad_a_s, float* grad_a_r,
-                  float* grad_w_alpha,
+                  float* grad_a_q, float* grad_w_alpha,
                   void* scratch_dev, size_t scratch_bytes, void* stream);
 
 /* ---- dense epilogue of a layer (inference): replaces models.py:41 (W_h + act), :81 (h0 index_copy_, as a

@@ -65,11 +65,11 @@ def lib():
     L.rg_layer_bwd_scratch_bytes.argtypes = [vp, vp, i32, i32]
     L.rg_layer_bwd_scratch_bytes.restype = sz
     L.rg_layer_bwd.argtypes = [vp, vp, i32, i64, vp, vp, i32, i32, vp, vp, vp, i32, vp, vp, i32,
-                               vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
+                               vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
     L.rg_tlayer_bwd_scratch_bytes.argtypes = [vp, vp, i32, i32]
     L.rg_tlayer_bwd_scratch_bytes.restype = sz
     L.rg_tlayer_bwd.argtypes = [vp, vp, i32, i64, vp, vp, vp, vp, i32, i32, vp, vp, vp, i32, vp, vp, i32,
-                                vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
+                                vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
     L.rg_dense_fwd_supported.argtypes = [i32, i32]
     L.rg_dense_fwd.argtypes = [i64, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, i32, vp, vp, vp]
     L.rg_rank.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp]

@@ -6,6 +6,13 @@ valid and test splits, one ``loader.shuffle_train()`` per epoch.  What differs i
 leave the device — ranking is ``rg_rank`` on CSR answer/filter lists instead of a host copy of ``[B, n_ent]`` scores and
 two scipy sorts per batch (base_model.py:106-118, utils.py:7-14) — and the NVML / RSS memory monitors of the reference
 (NVIDIA tooling) have no counterpart.
+
+Multi-GPU (the reference has none): with ``torch.distributed`` initialised (one process per GPU, same
+seed everywhere) every training batch is split over the ranks by query, each rank scales its loss to the global batch
+(the reference's loss carries a factor n = batch size), parameter gradients are summed with one flat all-reduce before
+``optimizer.step()``, and evaluation batches are dealt round-robin with four metric sums reduced at the end.  All ranks
+hold identical parameters after every step; with dropout = 0 the trajectory equals the single-process one up to fp32
+summation order.
 """
 import time
 
@@ -14,6 +21,7 @@ import torch
 from torch.optim import Adam
 from torch.optim.lr_scheduler import ExponentialLR
 
+from . import sharding
 from .models import RED_GNN_induc, RED_GNN_trans
 from .utils import cal_performance, cal_ranks_csr
 
@@ -35,8 +43,18 @@ def _chunks(n, size):
     return [np.arange(lo, min(lo + size, n)) for lo in range(0, n, size)]
 
 
+def _default_group():
+    import torch.distributed as dist
+    return dist if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 else None
+
+
 class BaseModel(object):
-    def __init__(self, args, loader):
+    def __init__(self, args, loader, dist="auto"):
+        """``dist``: a torch.distributed-like module (tests pass their own), None for single-process, or "auto" =
+        torch.distributed when a process group with more than one rank is initialised."""
+        self.dist = _default_group() if isinstance(dist, str) else dist
+        self.world = self.dist.get_world_size() if self.dist is not None else 1
+        self.rank = self.dist.get_rank() if self.dist is not None else 0
         # the inductive loader (two graphs) pairs with RED_GNN_induc (Static/inductive/base_model.py:14)
         net = RED_GNN_induc if getattr(loader, "inductive", False) else RED_GNN_trans
         self.model = net(args, loader).cuda()
@@ -58,18 +76,32 @@ class BaseModel(object):
         self.model.train()
         losses = []
         for idx in batches:
-            triple = self.loader.get_batch(idx)
+            lo, hi = sharding.shard_slice(len(idx), self.world, self.rank)
             self.model.zero_grad()
-            scores = self.model(triple[:, 0], triple[:, 1])
-            tails = torch.as_tensor(triple[:, 2], dtype=torch.long, device=scores.device)
-            loss = reference_loss(scores, tails)
-            loss.backward()
+            if hi > lo:
+                triple = self.loader.get_batch(idx[lo:hi])
+                scores = self.model(triple[:, 0], triple[:, 1])
+                tails = torch.as_tensor(triple[:, 2], dtype=torch.long, device=scores.device)
+                # the [n,n] broadcast of the reference's loss spans the whole batch: n_global x this rank's cross entropies
+                loss = reference_loss(scores, tails)
+                if self.world > 1:
+                    loss = loss * (len(idx) / (hi - lo))
+                loss.backward()
+                losses.append(loss.detach())
+            if self.dist is not None:
+                for p in self.model.parameters():          # a rank without queries still takes part in the all-reduce
+                    if p.grad is None:
+                        p.grad = torch.zeros_like(p)
+                sharding.allreduce_gradients(list(self.model.parameters()), self.dist)
             self.optimizer.step()
             self._scrub_nan()
-            losses.append(loss.detach())
         self.scheduler.step()
         self.t_time += time.time() - started
-        self.last_epoch_loss = float(torch.stack(losses).sum()) if losses else 0.0
+        device = next(self.model.parameters()).device
+        epoch_loss = torch.stack(losses).sum() if losses else torch.zeros((), device=device)
+        if self.dist is not None:
+            epoch_loss = sharding.reduce_metrics(epoch_loss.reshape(1), self.dist)[0]
+        self.last_epoch_loss = float(epoch_loss)
         valid_mrr, out_str = self.evaluate(epoch=epoch)
         self.loader.shuffle_train()
         return valid_mrr, out_str
@@ -85,16 +117,26 @@ class BaseModel(object):
         mode = self.loader.eval_mode(data) if hasattr(self.loader, "eval_mode") else data
         ranks = []
         with torch.no_grad():
-            for idx in _chunks(n_data, self.n_tbatch):
+            for idx in _chunks(n_data, self.n_tbatch)[self.rank::self.world]:       # evaluation batches dealt round-robin
                 subs, rels, ans_ptr, ans_idx, filt_ptr, filt_idx = self.loader.get_batch_csr(idx, data=data)
                 scores = self.model(subs, rels, mode=mode)
                 ranks.append(cal_ranks_csr(scores, ans_ptr, ans_idx, filt_ptr, filt_idx))
-        return torch.cat(ranks).double().cpu().numpy()
+        device = next(self.model.parameters()).device
+        return torch.cat(ranks).double() if ranks else torch.zeros(0, dtype=torch.float64, device=device)
+
+    def _performance(self, ranks):
+        """utils.cal_performance (utils.py:16-21); across ranks through the four sums it is made of."""
+        if self.dist is None:
+            return cal_performance(ranks.cpu().numpy())
+        sums = torch.stack([(1.0 / ranks).sum(), (ranks <= 1).sum().double(), (ranks <= 10).sum().double(),
+                            torch.tensor(float(ranks.numel()), dtype=torch.float64, device=ranks.device)])
+        sums = sharding.reduce_metrics(sums, self.dist).cpu().numpy()
+        return sums[0] / sums[3], sums[1] / sums[3], sums[2] / sums[3]
 
     def evaluate(self, epoch=-1):
         self.model.eval()
         started = time.time()
-        valid = cal_performance(self._rank_split("valid", self.n_valid))
-        test = cal_performance(self._rank_split("test", self.n_test))
+        valid = self._performance(self._rank_split("valid", self.n_valid))
+        test = self._performance(self._rank_split("test", self.n_test))
         i_time = time.time() - started
         return valid[0], _OUT_FMT % (*valid, *test, self.t_time, i_time)

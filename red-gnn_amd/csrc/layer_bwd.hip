@@ -16,6 +16,7 @@
 // Work distribution: walk.h (in-order per-XCD queues; grad_agg rows of the query being processed stay in L2).
 #include <stdlib.h>
 
+#include "aq_sum.h"
 #include "walk.h"
 
 namespace {
@@ -551,7 +552,7 @@ extern "C" int rg_layer_bwd(const rg_frontier* f, const rg_graph* g, int32_t lev
                             const float* rela, int32_t d, int32_t ld, const float* a_s, const float* a_r,
                             const float* a_q, int32_t ap, const float* w_alpha, const float* b_alpha, int32_t attn_dim,
                             const float* grad_agg, float* grad_hidden, float* grad_rela, float* grad_a_s,
-                            float* grad_a_r, float* grad_w_alpha, float* grad_b_alpha, void* scratch,
+                            float* grad_a_r, float* grad_a_q, float* grad_w_alpha, float* grad_b_alpha, void* scratch,
                             size_t scratch_bytes, void* stream) {
   RG_CHECK(f && g && hidden && rela && a_s && a_r && a_q && w_alpha && b_alpha && grad_agg && grad_hidden && grad_rela &&
                grad_a_s && grad_a_r && grad_w_alpha && grad_b_alpha, "rg_layer_bwd: NULL argument");
@@ -569,7 +570,7 @@ extern "C" int rg_layer_bwd(const rg_frontier* f, const rg_graph* g, int32_t lev
            "rg_layer_bwd: batch * hub segments overflows int32");
   const int64_t n_items = (int64_t)f->B * g->out_vr.n;
   RG_CHECK(n_items / 8 + ((int64_t)1 << 26) < ((int64_t)1 << 31), "rg_layer_bwd: work space too large for 32-bit queue tickets");
-  if (n_old == 0) return 0;
+  if (n_old == 0) return grad_a_q ? rg::launch_aq_sum(f->bm_of(level - 1), f->W, f->B, f->n_ent, 0, grad_a_s, ap, grad_a_q, (hipStream_t)stream) : 0;
   BwdArgs A;
   A.walk.n_items = n_items; A.walk.n_vrows = g->out_vr.n; A.walk.n_slots = g->out_vr.n_slots; A.walk.vrows = g->out_vr.rows;
   A.walk.bm_test = f->bm_of(level - 1); A.walk.W = f->W; A.walk.queues = f->counters + 16;
@@ -600,7 +601,9 @@ extern "C" int rg_layer_bwd(const rg_frontier* f, const rg_graph* g, int32_t lev
   else if (ld4 <= 16) rc = launch_ap<16>(A, ap / 4, f->B, g->out_vr, bm_old, dense, s);
   else if (ld4 <= 32) rc = launch_ap<32>(A, ap / 4, f->B, g->out_vr, bm_old, dense, s);
   else rc = launch_ap<64>(A, ap / 4, f->B, g->out_vr, bm_old, dense, s);
-  if (rc || (A.diag & 3)) return rc;
+  if (rc) return rc;
+  if (grad_a_q && rg::launch_aq_sum(bm_old, f->W, f->B, f->n_ent, n_old, grad_a_s, ap, grad_a_q, s)) return 1;
+  if (A.diag & 3) return 0;
   // relation gradient, relation-major (see drel_kernel)
   DrelArgs D;
   D.walk.n_items = (int64_t)f->B * g->rel_vr.n; D.walk.n_vrows = g->rel_vr.n; D.walk.n_slots = 0; D.walk.vrows = g->rel_vr.rows;

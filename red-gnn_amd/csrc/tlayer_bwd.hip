@@ -6,6 +6,7 @@
 //   d rela_dir / d time_dir rows += alpha G[o] (global float atomics: training batches of this model are small)
 //   g_alpha = <G[o], m_e>  ->  d a_s[s], d a_r[r], d w   exactly as in the static kernel.
 // The direction linears and the attention's three blocks are differentiated by the caller (dense GEMMs).
+#include "aq_sum.h"
 #include "walk.h"
 
 namespace {
@@ -334,7 +335,7 @@ extern "C" int rg_tlayer_bwd(const rg_frontier* f, const rg_graph* g, int32_t le
                              const float* a_s, const float* a_r, const float* a_q, int32_t ap, const float* w_alpha,
                              const float* b_alpha, int32_t attn_dim, const float* grad_agg, float* grad_hidden_dir,
                              float* grad_rela_dir, float* grad_time_dir, float* grad_a_s, float* grad_a_r,
-                             float* grad_w_alpha, void* scratch, size_t scratch_bytes, void* stream) {
+                             float* grad_a_q, float* grad_w_alpha, void* scratch, size_t scratch_bytes, void* stream) {
   RG_CHECK(f && g && q_time && hidden_dir && rela_dir && time_dir && a_s && a_r && a_q && w_alpha && b_alpha && grad_agg &&
                grad_hidden_dir && grad_rela_dir && grad_time_dir && grad_a_s && grad_a_r && grad_w_alpha,
            "rg_tlayer_bwd: NULL argument");
@@ -355,7 +356,7 @@ extern "C" int rg_tlayer_bwd(const rg_frontier* f, const rg_graph* g, int32_t le
            "rg_tlayer_bwd: batch * hub segments overflows int32");
   const int64_t n_items = (int64_t)f->B * g->out_vr.n;
   RG_CHECK(n_items / 8 + ((int64_t)1 << 26) < ((int64_t)1 << 31), "rg_tlayer_bwd: work space too large for 32-bit queue tickets");
-  if (n_old == 0) return 0;
+  if (n_old == 0) return grad_a_q ? rg::launch_aq_sum(f->bm_of(level - 1), f->W, f->B, f->n_ent, 0, grad_a_s, ap, grad_a_q, (hipStream_t)stream) : 0;
   TBwdArgs A;
   A.walk.n_items = n_items; A.walk.n_vrows = g->out_vr.n; A.walk.n_slots = g->out_vr.n_slots; A.walk.vrows = g->out_vr.rows;
   A.walk.bm_test = f->bm_of(level - 1); A.walk.W = f->W; A.walk.queues = f->counters + 16;
@@ -374,9 +375,12 @@ extern "C" int rg_tlayer_bwd(const rg_frontier* f, const rg_graph* g, int32_t le
   const bool dense = n_old >= 4 * (int64_t)f->B;
   const int ld4 = ld / 4;
   const int2* bm_old = f->bm_of(level - 1);
-  if (ld4 <= 4) return launch_ap<4>(A, ap / 4, f->B, g->out_vr, bm_old, dense, s);
-  if (ld4 <= 8) return launch_ap<8>(A, ap / 4, f->B, g->out_vr, bm_old, dense, s);
-  if (ld4 <= 16) return launch_ap<16>(A, ap / 4, f->B, g->out_vr, bm_old, dense, s);
-  if (ld4 <= 32) return launch_ap<32>(A, ap / 4, f->B, g->out_vr, bm_old, dense, s);
-  return launch_ap<64>(A, ap / 4, f->B, g->out_vr, bm_old, dense, s);
+  int rc;
+  if (ld4 <= 4) rc = launch_ap<4>(A, ap / 4, f->B, g->out_vr, bm_old, dense, s);
+  else if (ld4 <= 8) rc = launch_ap<8>(A, ap / 4, f->B, g->out_vr, bm_old, dense, s);
+  else if (ld4 <= 16) rc = launch_ap<16>(A, ap / 4, f->B, g->out_vr, bm_old, dense, s);
+  else if (ld4 <= 32) rc = launch_ap<32>(A, ap / 4, f->B, g->out_vr, bm_old, dense, s);
+  else rc = launch_ap<64>(A, ap / 4, f->B, g->out_vr, bm_old, dense, s);
+  if (rc) return rc;
+  return grad_a_q ? rg::launch_aq_sum(bm_old, f->W, f->B, f->n_ent, n_old, grad_a_s, ap, grad_a_q, s) : 0;
 }

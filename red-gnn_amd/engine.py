@@ -217,7 +217,7 @@ def layer_bwd(frontier, graph, level, nodes_old, hidden, rela, d, a_s, a_r, a_q,
     g_as = torch.empty_like(a_s)
     g_rela = torch.zeros_like(rela)
     g_ar = torch.zeros_like(a_r)
-    g_aq = torch.zeros_like(a_q)
+    g_aq = torch.empty_like(a_q)
     g_w = torch.zeros(attn_dim, dtype=torch.float32, device=dev)
     g_b = torch.zeros(1, dtype=torch.float32, device=dev)
     nbytes = _lib.lib().rg_layer_bwd_scratch_bytes(frontier.handle, graph.handle, ld, ap)
@@ -226,14 +226,14 @@ def layer_bwd(frontier, graph, level, nodes_old, hidden, rela, d, a_s, a_r, a_q,
                                        _lib.ptr(hidden), _lib.ptr(rela), d, ld, _lib.ptr(a_s), _lib.ptr(a_r),
                                        _lib.ptr(a_q), ap, _lib.ptr(w_alpha), _lib.ptr(b_alpha), attn_dim,
                                        _lib.ptr(grad_agg), _lib.ptr(g_h), _lib.ptr(g_rela), _lib.ptr(g_as),
-                                       _lib.ptr(g_ar), _lib.ptr(g_w), _lib.ptr(g_b), _lib.ptr(scratch), nbytes,
+                                       _lib.ptr(g_ar), _lib.ptr(g_aq), _lib.ptr(g_w), _lib.ptr(g_b), _lib.ptr(scratch), nbytes,
                                        _lib.stream_ptr()))
     return g_h, g_rela, g_as, g_ar, g_aq, g_w, g_b
 
 
 def tlayer_bwd(frontier, graph, level, n_old, q_time, hidden_dir, rela_dir, time_dir, d, a_s, a_r, a_q, w_alpha, b_alpha, attn_dim,
                grad_agg):
-    """Adjoint of tlayer_fwd (rg_tlayer_bwd).  Returns grads of (hidden_dir [3 n_old, ld], rela_dir, time_dir, a_s, a_r, w_alpha)."""
+    """Adjoint of tlayer_fwd (rg_tlayer_bwd).  Returns grads of (hidden_dir [3 n_old, ld], rela_dir, time_dir, a_s, a_r, a_q, w_alpha)."""
     ld, ap = hidden_dir.shape[1], a_s.shape[1]
     grad_agg = grad_agg.contiguous()
     dev = hidden_dir.device
@@ -242,15 +242,16 @@ def tlayer_bwd(frontier, graph, level, n_old, q_time, hidden_dir, rela_dir, time
     g_rd = torch.zeros_like(rela_dir)
     g_td = torch.zeros_like(time_dir)
     g_ar = torch.zeros_like(a_r)
+    g_aq = torch.empty_like(a_q)
     g_w = torch.zeros(attn_dim, dtype=torch.float32, device=dev)
     nbytes = _lib.lib().rg_tlayer_bwd_scratch_bytes(frontier.handle, graph.handle, ld, ap)
     scratch = frontier.scratch(nbytes)
     _lib.check(_lib.lib().rg_tlayer_bwd(frontier.handle, graph.handle, level, n_old, _lib.ptr(q_time), _lib.ptr(hidden_dir),
                                         _lib.ptr(rela_dir), _lib.ptr(time_dir), d, ld, _lib.ptr(a_s), _lib.ptr(a_r), _lib.ptr(a_q),
                                         ap, _lib.ptr(w_alpha), _lib.ptr(b_alpha), attn_dim, _lib.ptr(grad_agg), _lib.ptr(g_hd),
-                                        _lib.ptr(g_rd), _lib.ptr(g_td), _lib.ptr(g_as), _lib.ptr(g_ar), _lib.ptr(g_w),
+                                        _lib.ptr(g_rd), _lib.ptr(g_td), _lib.ptr(g_as), _lib.ptr(g_ar), _lib.ptr(g_aq), _lib.ptr(g_w),
                                         _lib.ptr(scratch), nbytes, _lib.stream_ptr()))
-    return g_hd, g_rd, g_td, g_as, g_ar, g_w
+    return g_hd, g_rd, g_td, g_as, g_ar, g_aq, g_w
 
 
 def dense_supported(d, attn_dim):

@@ -93,8 +93,6 @@ class _Aggregate(torch.autograd.Function):
         frontier, graph, level, d, attn_dim = ctx.misc
         g_h, g_rela, g_as, g_ar, g_aq, g_w, g_b = engine.layer_bwd(
             frontier, graph, level, nodes_old, hidden, rela, d, a_s, a_r, a_q, w_alpha, b_alpha, attn_dim, grad_agg)
-        # dA_q[b] = sum of dA_s over the nodes of query b (nodes are sorted by batch)
-        g_aq.index_add_(0, nodes_old[:, 0].long(), g_as)
         return g_h, g_rela, g_as, g_ar, g_aq, g_w.view_as(w_alpha), g_b.view_as(b_alpha), None, None, None, None, None, None, None
 
 

@@ -34,22 +34,21 @@ class _TAggregate(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, hidden_dir, rela_dir, time_dir, a_s, a_r, a_q, w_alpha, b_alpha, frontier, graph, level, n_new, q_time,
-                batch_old, d, attn_dim):
+                d, attn_dim):
         hidden_dir, rela_dir, time_dir, a_s, a_r, a_q, w_alpha = (t.contiguous() for t in (hidden_dir, rela_dir, time_dir, a_s, a_r, a_q, w_alpha))
         agg = engine.tlayer_fwd(frontier, graph, level, n_new, q_time, hidden_dir, rela_dir, time_dir, d, a_s, a_r, a_q,
                                 w_alpha, b_alpha, attn_dim)
-        ctx.save_for_backward(hidden_dir, rela_dir, time_dir, a_s, a_r, a_q, w_alpha, b_alpha, q_time, batch_old)
+        ctx.save_for_backward(hidden_dir, rela_dir, time_dir, a_s, a_r, a_q, w_alpha, b_alpha, q_time)
         ctx.misc = (frontier, graph, level, d, attn_dim)
         return agg
 
     @staticmethod
     def backward(ctx, grad_agg):
-        hidden_dir, rela_dir, time_dir, a_s, a_r, a_q, w_alpha, b_alpha, q_time, batch_old = ctx.saved_tensors
+        hidden_dir, rela_dir, time_dir, a_s, a_r, a_q, w_alpha, b_alpha, q_time = ctx.saved_tensors
         frontier, graph, level, d, attn_dim = ctx.misc
-        g_hd, g_rd, g_td, g_as, g_ar, g_w = engine.tlayer_bwd(frontier, graph, level, a_s.shape[0], q_time, hidden_dir, rela_dir,
+        g_hd, g_rd, g_td, g_as, g_ar, g_aq, g_w = engine.tlayer_bwd(frontier, graph, level, a_s.shape[0], q_time, hidden_dir, rela_dir,
                                                               time_dir, d, a_s, a_r, a_q, w_alpha, b_alpha, attn_dim, grad_agg)
-        g_aq = torch.zeros_like(a_q).index_add_(0, batch_old, g_as)       # nodes are sorted by query
-        return (g_hd, g_rd, g_td, g_as, g_ar, g_aq, g_w.view_as(w_alpha)) + (None,) * 9
+        return (g_hd, g_rd, g_td, g_as, g_ar, g_aq, g_w.view_as(w_alpha)) + (None,) * 8
 
 
 class T_RED_GNN(nn.Module):
@@ -120,7 +119,6 @@ class T_RED_GNN(nn.Module):
         time_dir = padc(F.linear(self.time_embed.weight, w_dir).view(self.n_time, 3, d).transpose(0, 1).reshape(3 * self.n_time, d)).contiguous()
         hidden = torch.zeros((n, d), device=device)
         zero_b = torch.zeros(1, device=device)
-        batch_old = torch.arange(n, device=device)
         n_edges, nodes = [], None
         for i in range(self.n_layer):
             rela, w1, w2 = self._tables(i)
@@ -134,15 +132,13 @@ class T_RED_GNN(nn.Module):
             w_alpha = w2.reshape(-1).contiguous()
             if with_grad:
                 agg = _TAggregate.apply(hidden_dir, rela_dir, time_dir, a_s, a_r, a_q, w_alpha, zero_b, fr, graph, fr.level, n_new,
-                                        q_time, batch_old, d, a)
+                                        q_time, d, a)
             else:
                 with torch.no_grad():
                     agg = engine.tlayer_fwd(fr, graph, fr.level, n_new, q_time, hidden_dir, rela_dir, time_dir, d, a_s, a_r, a_q,
                                             w_alpha, zero_b, a)
             hidden = self.act(self.dropout(agg[:, :d]))                               # model_cuda.py:196
-            if with_grad or i == self.n_layer - 1:
-                nodes, _, _ = fr.nodes(want_prev=False, want_old_new=False)
-                batch_old = nodes[:, 0].long()
+        nodes, _, _ = fr.nodes(want_prev=False, want_old_new=False)
         result = tall_linear(hidden, self.linear_classifier.weight, self.linear_classifier.bias).reshape(-1)   # model_cuda.py:210
         key_idx = nodes[:, 0].long() * self.n_ent + nodes[:, 1].long()
         score_all = torch.zeros(n * self.n_ent, device=device).index_copy(0, key_idx, result)

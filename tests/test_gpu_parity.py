@@ -7,6 +7,8 @@ rtol 1e-4 of the reference's CPU results, with atol 1e-5 on scores and 5e-5 on h
 reference's own sum order is unspecified, SURVEY.md §7 "Determinism / tolerance"), and
 rtol 2e-3 / atol 2e-5 on gradients (sums over every edge of the batch).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -302,7 +304,7 @@ def test_training_learns_on_family():
     torch.manual_seed(1234)
     bm = BaseModel(Opt, loader)
     bm.model.eval()
-    mrr0, _, _ = cal_performance(bm._rank_split("valid", 500))
+    mrr0, _, _ = bm._performance(bm._rank_split("valid", 500))
     bm.n_valid, bm.n_test = 500, 200            # keep the test short: evaluate on a slice
     mrr1, out = bm.train_batch(epoch=0, max_batches=150)
     assert np.isfinite(bm.last_epoch_loss)
@@ -616,8 +618,20 @@ def test_inductive_training_learns():
     assert isinstance(bm.model, RED_GNN_induc)
     bm.model.eval()
     from red_gnn_amd.utils import cal_performance
-    mrr0 = cal_performance(bm._rank_split("test", bm.n_test))[0]
+    mrr0 = bm._performance(bm._rank_split("test", bm.n_test))[0]
     for epoch in range(3):
         v_mrr, out = bm.train_batch(epoch=epoch)
     t_mrr = float(out.split("[TEST] MRR:")[1].split()[0])
     assert np.isfinite(bm.last_epoch_loss) and t_mrr > max(0.3, 2 * mrr0), (mrr0, out)
+
+
+def test_two_rank_training_matches_single_process():
+    """SURVEY §8e on the trainer: two processes (gloo, sharing this GPU) shard every batch by query, all-reduce gradients
+    and metric sums; parameters stay identical across ranks and track the single-process run (tools/dist_train_check.py)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(root, "tools", "dist_train_check.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0 and "DIST_TRAIN_CHECK_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]

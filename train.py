@@ -2,6 +2,8 @@
 
 Same two flags, same per-dataset hyper-parameter table, same 50-epoch loop and result files; the GPU is chosen by
 LOCAL_RANK / --gpu instead of parsing nvidia-smi (utils.select_gpu of the reference is NVIDIA tooling).
+Under ``python -m torch.distributed.run --nproc-per-node N train.py ...`` the batches are sharded by query over N GPUs
+(RCCL; see red_gnn_amd/base_model.py) and rank 0 writes the result files.
 """
 import argparse
 import os
@@ -44,6 +46,10 @@ def main():
     opts = Options()
     opts.perf_file = os.path.join("results", dataset + "_perf.txt")
     torch.cuda.set_device(args.gpu)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        torch.distributed.init_process_group("nccl")        # RCCL on ROCm
+    rank0 = world == 1 or torch.distributed.get_rank() == 0
     print("gpu:", args.gpu)
 
     loader = DataLoader(ids=dict(np.load(args.ids))) if args.ids else DataLoader(args.data_path)
@@ -52,20 +58,26 @@ def main():
      opts.n_batch, opts.n_tbatch) = PRESETS.get(dataset, PRESETS["family"])
     config_str = "%.4f, %.4f, %.6f,  %d, %d, %d, %d, %.4f,%s\n" % (
         opts.lr, opts.decay_rate, opts.lamb, opts.hidden_dim, opts.attn_dim, opts.n_layer, opts.n_batch, opts.dropout, opts.act)
-    print(config_str)
-    with open(opts.perf_file, "a+") as f:
-        f.write(config_str)
+    if rank0:
+        print(config_str)
+        with open(opts.perf_file, "a+") as f:
+            f.write(config_str)
 
     model = BaseModel(opts, loader)
     best_mrr, best_str = 0, ""
     for epoch in range(args.epochs):
         mrr, out_str = model.train_batch(epoch=epoch)
-        with open(opts.perf_file, "a+") as f:
-            f.write(out_str)
+        if rank0:
+            with open(opts.perf_file, "a+") as f:
+                f.write(out_str)
         if mrr > best_mrr:
             best_mrr, best_str = mrr, out_str
-            print(str(epoch) + "\t" + best_str)
-    print(best_str)
+            if rank0:
+                print(str(epoch) + "\t" + best_str)
+    if rank0:
+        print(best_str)
+    if world > 1:
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":
