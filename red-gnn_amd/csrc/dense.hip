@@ -17,67 +17,32 @@
 // which is exactly the set of accumulator rows the lane holds.  Weights stay in LDS for the whole
 // kernel (XOR-swizzled 16-B slots, conflict-free ds_read_b128); one persistent 8-wave workgroup per CU
 // (2 waves per SIMD: one wave's loads and transcendentals hide under the other's MFMAs).
-#include "common.h"
+#include "dense_common.h"
+
+using namespace rg;
 
 namespace {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-struct DenseArgs {
-  int64_t n;
-  int d, ld4;              // true width, row stride in float4
-  const float4* agg;
-  const float4* hprev;     // [n_old][ld4]
-  const int32_t* prev_idx; // [n] or null (all new)
-  const float* W_h;        // [d][d]
-  const float* w_ih;       // [3d][d]
-  const float* w_hh;
-  const float* b_ih;       // [3d]
-  const float* b_hh;
-  const float* Ws;         // [attn][d] or null
-  int attn, ap;
-  float* a_s_out;          // [n][ap]
-  const float* W_final;    // [d] or null
-  const int32_t* nodes;    // [n][2]
-  int n_ent;
-  float* scores;           // [B*n_ent]
-  float4* hidden_out;      // [n][ld4]
-  int act;                 // 0 idd, 1 relu, 2 tanh
-  int n_tiles;
-};
-
-// v_exp_f32 / v_rcp_f32 forms (1 ulp each; __builtin_amdgcn_rcpf, not the correctly rounded __frcp_rn which expands
-// to a full division): far inside the 1e-4 relative tolerance of the path
-__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
-__device__ __forceinline__ float fast_tanh(float x) {
-  const float e = __expf(-2.0f * fabsf(x));            // in (0, 1]: no overflow
-  return copysignf((1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e), x);
-}
 
 // LDS images: rows of DP floats, 16-B slot index XOR-swizzled with the row so that 16 lanes reading the same
 // logical slot of 16 different rows hit 16 different bank groups.
 template <int DP>
 __device__ __forceinline__ int sw(int row, int slot) { return row * (DP / 4) + (slot ^ (row & (DP / 4 - 1))); }
 
-// 8 waves per workgroup (2 per SIMD, <= 256 VGPRs) up to d = 64; at d = 128 the four 32-register fragments plus
-// accumulators need the whole 512-register file: 4 waves per workgroup, one per SIMD
-template <int NB> struct dense_cfg { static constexpr int T = NB <= 4 ? 512 : 256; static constexpr int WPS = NB <= 4 ? 2 : 1; };
+// 8 waves per workgroup (2 per SIMD, <= 256 VGPRs).  NB = DP / 16 in {2, 4}: d <= 64, where the 7 weight images fit LDS
+// (d = 128 streams them: dense128.hip).
+constexpr int DENSE_T = 512;
 
-// NB = DP / 16 in {2, 4, 8}.  WG (d = 128): the 448 KB of W_h / weight_ih / weight_hh do not fit LDS; the A fragments are
-// read straight from global memory (L2-resident, every CU streams the same rows) instead of an LDS image.
-template <int NB, bool WG>
-__global__ __launch_bounds__(dense_cfg<NB>::T, dense_cfg<NB>::WPS) void dense_kernel(DenseArgs A) {
-  constexpr int DENSE_T = dense_cfg<NB>::T;
+template <int NB>
+__global__ __launch_bounds__(DENSE_T, 2) void dense_kernel(DenseArgs A) {
   constexpr int DP = 16 * NB;      // padded width
   constexpr int S = DP / 4;        // 16-B slots per row
   constexpr int KS = DP / 4;       // MFMA k-steps per product = B-fragment registers
   constexpr int NW = DENSE_T / 64;
   extern __shared__ float4 lds[];
-  constexpr int WR = WG ? 0 : 1;              // weight images present in LDS?
   float4* Wh_l = lds;                         // [DP rows][S]
-  float4* Wih_l = Wh_l + WR * DP * S;         // [3*DP][S]   gate g rows at g*DP
-  float4* Whh_l = Wih_l + WR * 3 * DP * S;    // [3*DP][S]
-  float4* E_l = Whh_l + WR * 3 * DP * S;      // [32][S]     rows 0..ap-1 = Ws, row 16 = W_final
+  float4* Wih_l = Wh_l + DP * S;              // [3*DP][S]   gate g rows at g*DP
+  float4* Whh_l = Wih_l + 3 * DP * S;         // [3*DP][S]
+  float4* E_l = Whh_l + 3 * DP * S;           // [32][S]     rows 0..ap-1 = Ws, row 16 = W_final
   float* bias_l = reinterpret_cast<float*>(E_l + 32 * S);   // [4][DP]: b_ir+b_hr, b_iz+b_hz, b_in, b_hn
   float4* tiles = reinterpret_cast<float4*>(bias_l + 4 * DP);   // [NW waves][16 rows][S]
 
@@ -94,12 +59,10 @@ __global__ __launch_bounds__(dense_cfg<NB>::T, dense_cfg<NB>::WPS) void dense_ke
       dst[sw<DP>(row0_dst + r, sl)] = make_float4(v[0], v[1], v[2], v[3]);
     }
   };
-  if constexpr (!WG) {
-    load_w(Wh_l, A.W_h, d, 0, DP);
-    for (int g = 0; g < 3; ++g) {
-      load_w(Wih_l, A.w_ih + (int64_t)g * d * d, d, g * DP, DP);
-      load_w(Whh_l, A.w_hh + (int64_t)g * d * d, d, g * DP, DP);
-    }
+  load_w(Wh_l, A.W_h, d, 0, DP);
+  for (int g = 0; g < 3; ++g) {
+    load_w(Wih_l, A.w_ih + (int64_t)g * d * d, d, g * DP, DP);
+    load_w(Whh_l, A.w_hh + (int64_t)g * d * d, d, g * DP, DP);
   }
   load_w(E_l, A.Ws, A.Ws ? A.attn : 0, 0, 16);
   load_w(E_l, A.W_final, A.W_final ? 1 : 0, 16, 16);
@@ -128,11 +91,8 @@ __global__ __launch_bounds__(dense_cfg<NB>::T, dense_cfg<NB>::WPS) void dense_ke
       f[4 * ob + 0] = v.x; f[4 * ob + 1] = v.y; f[4 * ob + 2] = v.z; f[4 * ob + 3] = v.w;
     }
   };
-  // A fragment: 4 consecutive k of weight row `row` (LDS image, or the global matrix itself when WG: d == DP)
-  auto lda = [&](const float4* W_l, const float* W_g, int row, int slot) -> float4 {
-    if constexpr (WG) return *reinterpret_cast<const float4*>(W_g + (int64_t)row * DP + 4 * slot);
-    else return W_l[sw<DP>(row, slot)];
-  };
+  // A fragment: 4 consecutive k of weight row `row`
+  auto lda = [&](const float4* W_l, int row, int slot) -> float4 { return W_l[sw<DP>(row, slot)]; };
   // acc += W[row0 + (0..15)][:] . frag     (one 16-row block of a weight image)
   auto mma = [&](const float4* W_l, int row0, const float (&f)[KS], f32x4 acc) -> f32x4 {
 #pragma unroll
@@ -147,13 +107,12 @@ __global__ __launch_bounds__(dense_cfg<NB>::T, dense_cfg<NB>::WPS) void dense_ke
   };
   // three independent 16-row blocks against the same fragment, MFMAs interleaved so that no instruction
   // waits on its predecessor's accumulator (16x16x4 f32: 32-cycle issue, 40-cycle dependent latency)
-  auto mma3 = [&](const float4* Wl, const float* Wg, int r0, int r1, int r2, const float (&f)[KS],
-                  f32x4& c0, f32x4& c1, f32x4& c2) {
+  auto mma3 = [&](const float4* Wl, int r0, int r1, int r2, const float (&f)[KS], f32x4& c0, f32x4& c1, f32x4& c2) {
 #pragma unroll
     for (int kb = 0; kb < NB; ++kb) {
-      const float4 a0 = lda(Wl, Wg, r0 + li, 4 * kb + hq);
-      const float4 a1 = lda(Wl, Wg, r1 + li, 4 * kb + hq);
-      const float4 a2 = lda(Wl, Wg, r2 + li, 4 * kb + hq);
+      const float4 a0 = lda(Wl, r0 + li, 4 * kb + hq);
+      const float4 a1 = lda(Wl, r1 + li, 4 * kb + hq);
+      const float4 a2 = lda(Wl, r2 + li, 4 * kb + hq);
       c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, f[4 * kb + 0], c0, 0, 0, 0);
       c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, f[4 * kb + 0], c1, 0, 0, 0);
       c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.x, f[4 * kb + 0], c2, 0, 0, 0);
@@ -199,15 +158,14 @@ __global__ __launch_bounds__(dense_cfg<NB>::T, dense_cfg<NB>::WPS) void dense_ke
   // The two waves of a SIMD run the same program; started together they stay in lockstep (both in the MFMA phase,
   // then both in the transcendental/store phase, the matrix pipe idle).  Delaying the second half of the workgroup
   // by about half an MFMA phase lets one wave's epilogue run under the other's MFMAs (MI355X_MICROARCH.md, item 9).
-  if (NW > 4 && wv >= NW / 2) __builtin_amdgcn_s_sleep(127);
+  if (wv >= NW / 2) __builtin_amdgcn_s_sleep(127);
   float4 va[NL], vh[NL];
   bool has_old = false;
   const int t_step = gridDim.x * NW;
   int t = blockIdx.x * NW + wv;
-  if (NB <= 4 && t < A.n_tiles) load_tile(t, va, vh, has_old);
+  if (t < A.n_tiles) load_tile(t, va, vh, has_old);
   for (; t < A.n_tiles; t += t_step) {
     const int64_t row0 = (int64_t)t * 16;
-    if constexpr (NB > 4) load_tile(t, va, vh, has_old);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -232,8 +190,8 @@ __global__ __launch_bounds__(dense_cfg<NB>::T, dense_cfg<NB>::WPS) void dense_ke
     read_frag(hf);
     // a tile of new nodes only (every node of the early hops) has h = 0: its three W_hh products vanish
     const bool any_old = __ballot(has_old) != 0ull;
-    // next tile's loads fly under this tile's MFMAs (not at NB = 8: the fragments alone fill the register file)
-    if constexpr (NB <= 4) load_tile(t + t_step, va, vh, has_old);
+    // next tile's loads fly under this tile's MFMAs
+    load_tile(t + t_step, va, vh, has_old);
 
     // ---- stage 1: x = act(W_h agg)   (accumulators become the next B fragment) ---------------------------
     float xf[KS];
@@ -245,7 +203,7 @@ __global__ __launch_bounds__(dense_cfg<NB>::T, dense_cfg<NB>::WPS) void dense_ke
       for (int kb = 0; kb < NB; ++kb) {
         float4 a[NB];
 #pragma unroll
-        for (int ob = 0; ob < NB; ++ob) a[ob] = lda(Wh_l, A.W_h, 16 * ob + li, 4 * kb + hq);
+        for (int ob = 0; ob < NB; ++ob) a[ob] = lda(Wh_l, 16 * ob + li, 4 * kb + hq);
 #pragma unroll
         for (int ob = 0; ob < NB; ++ob) acc[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ob].x, fx[4 * kb + 0], acc[ob], 0, 0, 0);
 #pragma unroll
@@ -271,8 +229,8 @@ __global__ __launch_bounds__(dense_cfg<NB>::T, dense_cfg<NB>::WPS) void dense_ke
 #pragma unroll
     for (int ob = 0; ob < NB; ++ob) {
       f32x4 ar = bias_acc(0, ob), az = bias_acc(1, ob), ai = bias_acc(2, ob), ah = bias_acc(3, ob);
-      mma3(Wih_l, A.w_ih, 0 * DP + 16 * ob, 1 * DP + 16 * ob, 2 * DP + 16 * ob, xf, ar, az, ai);
-      if (any_old) mma3(Whh_l, A.w_hh, 0 * DP + 16 * ob, 1 * DP + 16 * ob, 2 * DP + 16 * ob, hf, ar, az, ah);
+      mma3(Wih_l, 0 * DP + 16 * ob, 1 * DP + 16 * ob, 2 * DP + 16 * ob, xf, ar, az, ai);
+      if (any_old) mma3(Whh_l, 0 * DP + 16 * ob, 1 * DP + 16 * ob, 2 * DP + 16 * ob, hf, ar, az, ah);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float rg = fast_sigmoid(ar[r]), zg = fast_sigmoid(az[r]);
@@ -312,14 +270,13 @@ __global__ __launch_bounds__(dense_cfg<NB>::T, dense_cfg<NB>::WPS) void dense_ke
   }
 }
 
-template <int NB, bool WG>
+template <int NB>
 int launch(const DenseArgs& A, hipStream_t s) {
-  constexpr int DENSE_T = dense_cfg<NB>::T;
   constexpr int DP = 16 * NB, S = DP / 4, NW = DENSE_T / 64;
-  const size_t lds = (size_t)((WG ? 0 : 7 * DP * S) + 32 * S) * sizeof(float4) + 4 * DP * sizeof(float) + (size_t)NW * 16 * S * sizeof(float4);
-  RG_HIP(hipFuncSetAttribute((const void*)dense_kernel<NB, WG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const size_t lds = (size_t)(7 * DP * S + 32 * S) * sizeof(float4) + 4 * DP * sizeof(float) + (size_t)NW * 16 * S * sizeof(float4);
+  RG_HIP(hipFuncSetAttribute((const void*)dense_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int grid = (int)std::min<int64_t>(rg::ceil_div(A.n_tiles, NW), 256);
-  hipLaunchKernelGGL((dense_kernel<NB, WG>), dim3(grid), dim3(DENSE_T), lds, s, A);
+  hipLaunchKernelGGL((dense_kernel<NB>), dim3(grid), dim3(DENSE_T), lds, s, A);
   RG_LAUNCH_CHECK();
   return 0;
 }
@@ -353,6 +310,6 @@ extern "C" int rg_dense_fwd(int64_t n, int32_t d, int32_t ld, const float* agg, 
   A.hidden_out = (float4*)hidden_out; A.act = act;
   A.n_tiles = (int)rg::ceil_div(n, 16);
   hipStream_t s = (hipStream_t)stream;
-  if (d == 128) return launch<8, true>(A, s);
-  return d <= 32 ? launch<2, false>(A, s) : launch<4, false>(A, s);
+  if (d == 128) return rg::dense128_launch(A, s);
+  return d <= 32 ? launch<2>(A, s) : launch<4>(A, s);
 }

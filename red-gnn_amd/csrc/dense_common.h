@@ -1,0 +1,44 @@
+// Shared by the fused dense kernels (dense.hip: d <= 64 with the weights resident in LDS; dense128.hip: d = 128 with the
+// weights streamed through LDS).
+#pragma once
+#include "common.h"
+
+namespace rg {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct DenseArgs {
+  int64_t n;
+  int d, ld4;              // true width, row stride in float4
+  const float4* agg;
+  const float4* hprev;     // [n_old][ld4]
+  const int32_t* prev_idx; // [n] or null (all new)
+  const float* W_h;        // [d][d]
+  const float* w_ih;       // [3d][d]
+  const float* w_hh;
+  const float* b_ih;       // [3d]
+  const float* b_hh;
+  const float* Ws;         // [attn][d] or null
+  int attn, ap;
+  float* a_s_out;          // [n][ap]
+  const float* W_final;    // [d] or null
+  const int32_t* nodes;    // [n][2]
+  int n_ent;
+  float* scores;           // [B*n_ent]
+  float4* hidden_out;      // [n][ld4]
+  int act;                 // 0 idd, 1 relu, 2 tanh
+  int n_tiles;
+};
+
+// v_exp_f32 / v_rcp_f32 forms (1 ulp each; __builtin_amdgcn_rcpf, not the correctly rounded __frcp_rn which expands
+// to a full division): far inside the 1e-4 relative tolerance of the path
+static __device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+static __device__ __forceinline__ float fast_tanh(float x) {
+  const float e = __expf(-2.0f * fabsf(x));            // in (0, 1]: no overflow
+  return copysignf((1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e), x);
+}
+
+// d = 128 (dense128.hip)
+int dense128_launch(const DenseArgs& A, hipStream_t s);
+
+}  // namespace rg
