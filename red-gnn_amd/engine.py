@@ -254,6 +254,24 @@ def tlayer_bwd(frontier, graph, level, n_old, q_time, hidden_dir, rela_dir, time
     return g_hd, g_rd, g_td, g_as, g_ar, g_aq, g_w
 
 
+_BLAS_CHOICE = [None]
+
+
+def prefer_blas(n_rows):
+    """Pick the GEMM library for the torch-side dense algebra of a training step from the number of node rows.
+    hipBLASLt (torch's default on gfx950) searches its heuristics again for every new problem size: 75 us per call
+    when the row count changes with every batch, as it does here, against 11 us through rocBLAS (tools/probe_small_gemm.py);
+    with the family preset (20 queries per batch) that search was half of the step.  For millions of rows the batched
+    weight-gradient products are 1.5x faster through hipBLASLt, and the call overhead no longer matters."""
+    choice = "cublas" if n_rows < (1 << 17) else "cublaslt"      # torch's names: cublas = rocBLAS, cublaslt = hipBLASLt
+    if _BLAS_CHOICE[0] != choice:
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            torch.backends.cuda.preferred_blas_library(choice)
+        _BLAS_CHOICE[0] = choice
+
+
 def dense_supported(d, attn_dim):
     return bool(_lib.lib().rg_dense_fwd_supported(d, attn_dim))
 

@@ -193,6 +193,7 @@ class RED_GNN_trans(nn.Module):
             n_new, n_e, _ = fr.expand(graph)                                     # models.py:78 (on the device)
             nodes, _, old_new = fr.nodes(want_prev=False)
             n_edges.append(n_e)
+            engine.prefer_blas(n_new)
             hidden = self.gnn_layers[i](q_sub, q_rel, hidden, fr, graph, fr.level, nodes, nodes_old)   # models.py:80
             h0 = torch.zeros((n_new, d), device=device).index_copy(0, old_new.long(), h0)           # models.py:81
             hidden = self.dropout(hidden)                                        # models.py:82

@@ -124,6 +124,8 @@ class T_RED_GNN(nn.Module):
             rela, w1, w2 = self._tables(i)
             n_new, n_e, n_old = fr.expand(graph)
             n_edges.append(n_e)
+            if with_grad:
+                engine.prefer_blas(n_new)
             a_s = tall_linear(hidden, pad_rows(w1[:, :d])).contiguous()               # [n_old, ap]
             a_r = F.linear(rela, pad_rows(w1[:, d:2 * d])).contiguous()              # [n_rel+1, ap]
             a_q = F.linear(rela[q_rel], pad_rows(w1[:, 2 * d:])).contiguous()        # [B, ap]

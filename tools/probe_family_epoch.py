@@ -1,6 +1,7 @@
 """Host-side cost of the reference's training loop on the real family graph (preset: B=20, d=48)."""
 import os, sys, time, cProfile, pstats
 import numpy as np, torch
+if os.environ.get('RG_BLAS'): torch.backends.cuda.preferred_blas_library(os.environ['RG_BLAS'])
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from red_gnn_amd.base_model import BaseModel
 from red_gnn_amd.load_data import DataLoader

@@ -1,6 +1,7 @@
 """Timing probe: one training step (forward + reference loss + HIP backward + Adam) on a BASELINE shape."""
 import sys, time, os
 import numpy as np, torch
+if os.environ.get('RG_BLAS'): torch.backends.cuda.preferred_blas_library(os.environ['RG_BLAS'])
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from red_gnn_amd.base_model import reference_loss
 from red_gnn_amd.load_data import DataLoader
