@@ -635,3 +635,34 @@ def test_two_rank_training_matches_single_process():
            "--master-port", "29533", os.path.join(root, "tools", "dist_train_check.py")]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0 and "DIST_TRAIN_CHECK_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def test_nan_scrub_replaces_only_nans_and_consumes_one_draw_per_parameter():
+    """base_model.py:64-69 of the reference: X[np.isnan(X)] = np.random.random() for every parameter after each step."""
+    from red_gnn_amd.base_model import BaseModel
+    from red_gnn_amd.load_data import DataLoader
+    from red_gnn_amd.synthetic import make_synthetic_kg
+    kg = make_synthetic_kg(60, 4, 400, seed=2)
+    loader = DataLoader(ids=dict(n_ent=kg.n_ent, n_rel=kg.n_rel, facts=kg.facts, train=kg.train, valid=kg.valid, test=kg.test), verbose=False)
+
+    class Opt:
+        lr, decay_rate, lamb, hidden_dim, attn_dim, n_layer, dropout, act, n_batch, n_tbatch = 0.01, 0.99, 1e-5, 16, 3, 2, 0.0, "relu", 8, 8
+        n_rel = loader.n_rel
+
+    bm = BaseModel(Opt, loader)
+    params = list(bm.model.parameters())
+    with torch.no_grad():
+        params[0].data[0, 0] = float("nan")
+        params[0].data[0, 1] = float("inf")
+        params[3].data.view(-1)[2] = float("nan")
+    before = [p.detach().clone() for p in params]
+    np.random.seed(99)
+    draws = [np.random.random() for _ in params]
+    np.random.seed(99)
+    bm._scrub_nan()
+    assert np.random.random() == np.random.RandomState(99).random_sample(len(params) + 1)[-1]      # one draw per parameter
+    assert params[0].data[0, 0].item() == pytest.approx(draws[0]) and params[0].data[0, 1].item() == float("inf")
+    assert params[3].data.view(-1)[2].item() == pytest.approx(draws[3])
+    for p, b in zip(params, before):
+        keep = ~torch.isnan(b)
+        assert torch.equal(p.data[keep], b[keep])
