@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--config", default="C2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--graphs", action="store_true", help="replay the forward as a captured HIP graph (no per-kernel HIP events, so no roofline object)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group even at world size 1 (exercises the RCCL path on one GPU)")
     args = ap.parse_args()
 
@@ -109,6 +110,7 @@ def main():
     loader = DataLoader(ids=ids, verbose=False)
     torch.manual_seed(1234)
     model = RED_GNN_trans(Params(shape, kg.n_rel), loader).cuda().eval()
+    model.use_graphs = args.graphs            # the default run keeps the eager path: its kernels are timed one by one below
     d = shape["hidden_dim"]
 
     B = args.batch
@@ -118,7 +120,7 @@ def main():
     subs, rels, a_ptr, a_idx, f_ptr, f_idx = loader.get_batch_csr(q_idx, data="test")
 
     kernel_events, dense_events = [], []
-    if not args.no_kernel_events:
+    if not args.no_kernel_events and not args.graphs:
         engine.KERNEL_EVENTS = kernel_events
         engine.DENSE_EVENTS = dense_events
 

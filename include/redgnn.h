@@ -72,6 +72,15 @@ int rg_frontier_reset_nodes(rg_frontier* f, const int32_t* nodes_dev, int64_t n,
  * old nodes).  counts_host[0] = N_new, counts_host[1] = E (edges of this hop),
  * counts_host[2] = N_old, counts_host[3] = new level.  Synchronises `stream`. */
 int rg_frontier_expand(rg_frontier* f, const rg_graph* g, int64_t* counts_host, void* stream);
+/* The same hop without the read-back: nothing synchronises, so a whole forward (models.py:69-88) can be enqueued - or
+ * captured into a hipGraph - in one go.  The level's N stays on the device (rg_frontier_count_ptr; consumed by
+ * rg_dense_fwd_dev), and while a level's size is unknown on the host rg_layer_fwd / rg_tlayer_fwd take their n_new as
+ * an estimate (> 0, it only picks the walk) and need agg_out sized for batch * n_ent rows.
+ * rg_frontier_level_counts reads N and E of levels 0..current back: counts_host[2*l] = N_l, [2*l+1] = E_l
+ * (room for 2 * 16 values; synchronises `stream`). */
+int rg_frontier_expand_async(rg_frontier* f, const rg_graph* g, void* stream);
+const int32_t* rg_frontier_count_ptr(const rg_frontier* f);
+int rg_frontier_level_counts(const rg_frontier* f, int64_t* counts_host, void* stream);
 /* nodes of the current level: nodes_out int32 [N_new,2] = (batch, entity) sorted
  * (== tail_nodes, load_data.py:123); prev_idx_out int32 [N_new] = index of the node in the
  * previous level or -1; old_nodes_new_idx_out int32 [N_old] (load_data.py:127-129).
@@ -177,6 +186,15 @@ int rg_rank(const float* scores, int32_t batch, int32_t n_ent,
             const int32_t* ans_ptr, const int32_t* ans_idx,
             const int32_t* filt_ptr, const int32_t* filt_idx,
             float* ranks_out, void* stream);
+
+/* rg_dense_fwd with the node count read on the device (after rg_frontier_expand_async): n_cap = capacity of the row buffers,
+ * n_dev = rg_frontier_count_ptr() of the frontier whose newest level the rows belong to. */
+int rg_dense_fwd_dev(int64_t n_cap, const int32_t* n_dev, int32_t d, int32_t ld, const float* agg, const float* hidden_prev,
+                     const int32_t* prev_idx, const float* W_h, int32_t act,
+                     const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                     const float* Ws_next, int32_t attn_dim, int32_t ap, float* a_s_out,
+                     const float* W_final, const int32_t* nodes, int32_t n_ent, float* scores_all,
+                     float* hidden_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -15,7 +15,8 @@ SYMBOLS = [
     "rg_graph_create", "rg_tgraph_create", "rg_graph_destroy", "rg_graph_n_fact", "rg_graph_export",
     "rg_frontier_workspace_bytes", "rg_frontier_create", "rg_frontier_destroy", "rg_frontier_reset",
     "rg_frontier_reset_nodes", "rg_frontier_expand", "rg_frontier_nodes", "rg_frontier_edges_scratch_bytes", "rg_frontier_edges",
-    "rg_layer_fwd_scratch_bytes", "rg_layer_fwd", "rg_tlayer_fwd", "rg_layer_bwd_scratch_bytes", "rg_layer_bwd", "rg_tlayer_bwd_scratch_bytes", "rg_tlayer_bwd", "rg_dense_fwd_supported", "rg_dense_fwd", "rg_rank",
+    "rg_layer_fwd_scratch_bytes", "rg_layer_fwd", "rg_tlayer_fwd", "rg_layer_bwd_scratch_bytes", "rg_layer_bwd", "rg_tlayer_bwd_scratch_bytes", "rg_tlayer_bwd", "rg_dense_fwd_supported", "rg_dense_fwd", "rg_dense_fwd_dev", "rg_rank",
+    "rg_frontier_expand_async", "rg_frontier_count_ptr", "rg_frontier_level_counts",
 ]
 
 _lib = None
@@ -54,6 +55,10 @@ def lib():
     L.rg_frontier_reset.argtypes = [vp, vp, vp]
     L.rg_frontier_reset_nodes.argtypes = [vp, vp, i64, vp]
     L.rg_frontier_expand.argtypes = [vp, vp, C.POINTER(i64), vp]
+    L.rg_frontier_expand_async.argtypes = [vp, vp, vp]
+    L.rg_frontier_count_ptr.argtypes = [vp]
+    L.rg_frontier_count_ptr.restype = vp
+    L.rg_frontier_level_counts.argtypes = [vp, C.POINTER(i64), vp]
     L.rg_frontier_nodes.argtypes = [vp, vp, vp, vp, vp]
     L.rg_frontier_edges_scratch_bytes.argtypes = [i64]
     L.rg_frontier_edges_scratch_bytes.restype = sz
@@ -72,6 +77,7 @@ def lib():
                                 vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
     L.rg_dense_fwd_supported.argtypes = [i32, i32]
     L.rg_dense_fwd.argtypes = [i64, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, i32, vp, vp, vp]
+    L.rg_dense_fwd_dev.argtypes = [i64, vp, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, i32, vp, vp, vp]
     L.rg_rank.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp]
     _lib = L
     return L

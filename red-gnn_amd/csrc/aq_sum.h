@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void aq_sum_kernel(const int2* __restrict__ bm
 // grad_a_q [B, ap] is WRITTEN (zero-filled here)
 static inline int launch_aq_sum(const int2* bm_old, int W, int B, int32_t n_ent, int64_t n_old, const float* g_as, int ap,
                                 float* g_aq, hipStream_t s) {
-  RG_HIP(hipMemsetAsync(g_aq, 0, (size_t)B * ap * sizeof(float), s));
+  if (zero_async(g_aq, (size_t)B * ap * sizeof(float), s)) return 1;
   if (n_old == 0) return 0;
   const dim3 grid((unsigned)B, (unsigned)ceil_div(n_ent, AQ_ROWS));
   hipLaunchKernelGGL(aq_sum_kernel, grid, dim3(256), 0, s, bm_old, W, B, n_old, (const float4*)g_as, ap / 4, g_aq);

@@ -31,6 +31,13 @@ void set_error(const char* fmt, ...);
 
 #define RG_LAUNCH_CHECK() RG_HIP(hipGetLastError())
 
+// Device fills and small device-to-device copies as plain kernels.  hipMemsetAsync / hipMemcpyAsync would do, except inside a
+// captured hipGraph: with ROCm 7.2 a graph holding several memset nodes zeroes correctly on its first launch only (later
+// launches left stale bitmap words and wrote address-like garbage into the 1 KB counter block; tools/probe_graph.py), so
+// every fill that can end up in a graph goes through these.  p 4-byte aligned, bytes a multiple of 4.
+int zero_async(void* p, size_t bytes, hipStream_t s);
+int copy_words_async(void* dst, const void* src, int n_words, hipStream_t s);
+
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

@@ -39,6 +39,7 @@ __global__ __launch_bounds__(DENSE_T, 2) void dense_kernel(DenseArgs A) {
   constexpr int KS = DP / 4;       // MFMA k-steps per product = B-fragment registers
   constexpr int NW = DENSE_T / 64;
   extern __shared__ float4 lds[];
+  if (A.n_dev) { A.n = *A.n_dev; A.n_tiles = (int)((A.n + 15) / 16); }      // the grid was sized for the capacity
   float4* Wh_l = lds;                         // [DP rows][S]
   float4* Wih_l = Wh_l + DP * S;              // [3*DP][S]   gate g rows at g*DP
   float4* Whh_l = Wih_l + 3 * DP * S;         // [3*DP][S]
@@ -285,11 +286,11 @@ int launch(const DenseArgs& A, hipStream_t s) {
 
 extern "C" int rg_dense_fwd_supported(int32_t d, int32_t attn_dim) { return ((d >= 1 && d <= 64) || d == 128) && attn_dim <= 16; }
 
-extern "C" int rg_dense_fwd(int64_t n, int32_t d, int32_t ld, const float* agg, const float* hidden_prev,
-                            const int32_t* prev_idx, const float* W_h, int32_t act, const float* w_ih, const float* w_hh,
-                            const float* b_ih, const float* b_hh, const float* Ws_next, int32_t attn_dim, int32_t ap,
-                            float* a_s_out, const float* W_final, const int32_t* nodes, int32_t n_ent, float* scores_all,
-                            float* hidden_out, void* stream) {
+static int dense_fwd_impl(int64_t n, const int32_t* n_dev, int32_t d, int32_t ld, const float* agg, const float* hidden_prev,
+                          const int32_t* prev_idx, const float* W_h, int32_t act, const float* w_ih, const float* w_hh,
+                          const float* b_ih, const float* b_hh, const float* Ws_next, int32_t attn_dim, int32_t ap,
+                          float* a_s_out, const float* W_final, const int32_t* nodes, int32_t n_ent, float* scores_all,
+                          float* hidden_out, void* stream) {
   RG_CHECK(agg && W_h && w_ih && w_hh && b_ih && b_hh && hidden_out, "rg_dense_fwd: NULL argument");
   RG_CHECK(!prev_idx || hidden_prev, "rg_dense_fwd: prev_idx given without hidden_prev");
   RG_CHECK((d >= 1 && d <= 64) || d == 128, "rg_dense_fwd: hidden_dim %d not supported by the fused kernel (<= 64, or 128)", d);
@@ -302,7 +303,7 @@ extern "C" int rg_dense_fwd(int64_t n, int32_t d, int32_t ld, const float* agg, 
            "rg_dense_fwd: float buffers must be 16-B aligned");
   if (n == 0) return 0;
   DenseArgs A;
-  A.n = n; A.d = d; A.ld4 = ld / 4;
+  A.n = n; A.n_dev = n_dev; A.d = d; A.ld4 = ld / 4;
   A.agg = (const float4*)agg; A.hprev = (const float4*)hidden_prev; A.prev_idx = prev_idx;
   A.W_h = W_h; A.w_ih = w_ih; A.w_hh = w_hh; A.b_ih = b_ih; A.b_hh = b_hh;
   A.Ws = Ws_next; A.attn = attn_dim; A.ap = ap; A.a_s_out = a_s_out;
@@ -312,4 +313,23 @@ extern "C" int rg_dense_fwd(int64_t n, int32_t d, int32_t ld, const float* agg, 
   hipStream_t s = (hipStream_t)stream;
   if (d == 128) return rg::dense128_launch(A, s);
   return d <= 32 ? launch<2>(A, s) : launch<4>(A, s);
+}
+
+extern "C" int rg_dense_fwd(int64_t n, int32_t d, int32_t ld, const float* agg, const float* hidden_prev,
+                            const int32_t* prev_idx, const float* W_h, int32_t act, const float* w_ih, const float* w_hh,
+                            const float* b_ih, const float* b_hh, const float* Ws_next, int32_t attn_dim, int32_t ap,
+                            float* a_s_out, const float* W_final, const int32_t* nodes, int32_t n_ent, float* scores_all,
+                            float* hidden_out, void* stream) {
+  return dense_fwd_impl(n, nullptr, d, ld, agg, hidden_prev, prev_idx, W_h, act, w_ih, w_hh, b_ih, b_hh, Ws_next, attn_dim, ap,
+                        a_s_out, W_final, nodes, n_ent, scores_all, hidden_out, stream);
+}
+
+extern "C" int rg_dense_fwd_dev(int64_t n_cap, const int32_t* n_dev, int32_t d, int32_t ld, const float* agg,
+                                const float* hidden_prev, const int32_t* prev_idx, const float* W_h, int32_t act,
+                                const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, const float* Ws_next,
+                                int32_t attn_dim, int32_t ap, float* a_s_out, const float* W_final, const int32_t* nodes,
+                                int32_t n_ent, float* scores_all, float* hidden_out, void* stream) {
+  RG_CHECK(n_dev != nullptr, "rg_dense_fwd_dev: n_dev is NULL");
+  return dense_fwd_impl(n_cap, n_dev, d, ld, agg, hidden_prev, prev_idx, W_h, act, w_ih, w_hh, b_ih, b_hh, Ws_next, attn_dim, ap,
+                        a_s_out, W_final, nodes, n_ent, scores_all, hidden_out, stream);
 }

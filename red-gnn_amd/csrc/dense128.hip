@@ -27,6 +27,7 @@ __device__ __forceinline__ int swz(int row, int slot) { return row * S + (slot ^
 
 __global__ __launch_bounds__(T, 2) void dense128_kernel(DenseArgs A) {
   extern __shared__ float4 lds[];
+  if (A.n_dev) { A.n = *A.n_dev; A.n_tiles = (int)((A.n + 15) / 16); }      // the grid was sized for the capacity
   float4* wbuf = lds;                                            // [2][CHUNK]
   float4* E_l = wbuf + 2 * CHUNK;                                // [32][S]  rows 0..ap-1 = Ws, row 16 = W_final
   float* bias_l = reinterpret_cast<float*>(E_l + 32 * S);        // [4][DP]: b_ir+b_hr, b_iz+b_hz, b_in, b_hn

@@ -8,7 +8,8 @@ namespace rg {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct DenseArgs {
-  int64_t n;
+  int64_t n;               // number of node rows, or their capacity when n_dev is given
+  const int32_t* n_dev;    // device-side count (after rg_frontier_expand_async), or null
   int d, ld4;              // true width, row stride in float4
   const float4* agg;
   const float4* hprev;     // [n_old][ld4]

@@ -191,7 +191,7 @@ size_t ws_layout(int32_t n_ent, int32_t B, int32_t n_levels, size_t* off /*[8]*/
   off[2] = take((size_t)B * W * 4);                          // words_tmp
   off[3] = take((size_t)B * W * 4);                          // prefix_tmp
   off[4] = take(rg::scan_scratch_elems((int64_t)B * W) * 4); // scan scratch
-  off[5] = take(256);                                        // counters + work queues
+  off[5] = take(1024);                                       // counters, work queues, per-level snapshots
   off[6] = take((size_t)n_levels * B * W * 8);               // bm levels
   return o;
 }
@@ -227,7 +227,7 @@ int rg_frontier_create(int32_t n_ent, int32_t batch, int32_t n_levels, void* ws,
   f->scan_scratch = (int32_t*)(base + off[4]);
   f->counters = (int32_t*)(base + off[5]);
   for (int l = 0; l < n_levels; ++l) f->bm[l] = (int2*)(base + off[6] + (size_t)l * batch * f->W * 8);
-  if (hipHostMalloc((void**)&f->counts_pinned, 8 * sizeof(int64_t), hipHostMallocDefault) != hipSuccess) {
+  if (hipHostMalloc((void**)&f->counts_pinned, 1024, hipHostMallocDefault) != hipSuccess) {
     delete f;
     rg::set_error("rg_frontier_create: hipHostMalloc failed");
     return 1;
@@ -262,13 +262,12 @@ int rg_frontier_reset(rg_frontier* f, const int32_t* q_sub, void* stream) {
   RG_CHECK(f && q_sub, "rg_frontier_reset: NULL argument");
   hipStream_t s = (hipStream_t)stream;
   f->level = 0; f->tcur = 0; f->n_edges = 0;
-  RG_HIP(hipMemsetAsync(f->bitsT[0], 0, (size_t)f->n_ent * f->BW * 4, s));
-  RG_HIP(hipMemsetAsync(f->counters, 0, 256, s));
+  if (rg::zero_async(f->bitsT[0], (size_t)f->n_ent * f->BW * 4, s) || rg::zero_async(f->counters, 1024, s)) return 1;
   hipLaunchKernelGGL(reset_kernel, dim3(rg::ceil_div(f->B, 256)), dim3(256), 0, s, q_sub, f->B, f->n_ent, f->BW,
                      f->bitsT[0], f->counters);
   RG_LAUNCH_CHECK();
   if (build_level(f, s)) return 1;
-  RG_HIP(hipMemcpyAsync(&f->counters[4], &f->counters[0], 4, hipMemcpyDeviceToDevice, s));
+  if (rg::copy_words_async(&f->counters[4], &f->counters[0], 1, s)) return 1;
   f->n_nodes[0] = f->B;   // one node per query; an out-of-range q_sub is reported by the next expand
   return 0;
 }
@@ -277,16 +276,38 @@ int rg_frontier_reset_nodes(rg_frontier* f, const int32_t* nodes, int64_t n, voi
   RG_CHECK(f && (nodes || n == 0) && n >= 0, "rg_frontier_reset_nodes: bad argument");
   hipStream_t s = (hipStream_t)stream;
   f->level = 0; f->tcur = 0; f->n_edges = 0;
-  RG_HIP(hipMemsetAsync(f->bitsT[0], 0, (size_t)f->n_ent * f->BW * 4, s));
-  RG_HIP(hipMemsetAsync(f->counters, 0, 256, s));
+  if (rg::zero_async(f->bitsT[0], (size_t)f->n_ent * f->BW * 4, s) || rg::zero_async(f->counters, 1024, s)) return 1;
   if (n > 0) {
     hipLaunchKernelGGL(reset_nodes_kernel, dim3(rg::ceil_div(n, 256)), dim3(256), 0, s, nodes, n, f->B, f->n_ent, f->BW,
                        f->bitsT[0], f->counters);
     RG_LAUNCH_CHECK();
   }
   if (build_level(f, s)) return 1;
-  RG_HIP(hipMemcpyAsync(&f->counters[4], &f->counters[0], 4, hipMemcpyDeviceToDevice, s));
+  if (rg::copy_words_async(&f->counters[4], &f->counters[0], 1, s)) return 1;
   f->n_nodes[0] = n;   // duplicates or out-of-range ids are reported by the next expand
+  return 0;
+}
+
+// enqueue one expansion: bitsT[tcur] -> bitsT[tcur^1] -> bm[level+1]; N and E of the new level are left in counters[0], [2..3]
+// and snapshotted into counters[64 + 8*level ..] for rg_frontier_level_counts
+static int enqueue_expand(rg_frontier* f, const rg_graph* g, hipStream_t s) {
+  const uint32_t* oldT = f->bitsT[f->tcur];
+  uint32_t* newT = f->bitsT[f->tcur ^ 1];
+  int WL = 1;
+  while (WL < f->BW && WL < 64) WL <<= 1;
+  if (rg::zero_async(&f->counters[2], 8, s)) return 1;
+  hipLaunchKernelGGL(count_edges_kernel, dim3(rg::ceil_div((int64_t)f->n_ent * f->BW, 256)), dim3(256), 0, s, g->out_ptr,
+                     oldT, f->n_ent, f->BW, (unsigned long long*)&f->counters[2]);
+  RG_LAUNCH_CHECK();
+  if (rg::zero_async(newT, (size_t)f->n_ent * f->BW * 4, s)) return 1;
+  hipLaunchKernelGGL(hop_or_kernel, dim3(rg::ceil_div(g->in_vr.n, 4)), dim3(256), 0, s, g->in_vr.rows, g->in_vr.n, g->in_hr,
+                     oldT, newT, f->BW, WL);
+  RG_LAUNCH_CHECK();
+  f->tcur ^= 1;
+  f->level += 1;
+  if (build_level(f, s)) return 1;
+  if (f->level < RG_MAX_LEVELS)
+    if (rg::copy_words_async(&f->counters[64 + 8 * f->level], f->counters, 4, s)) return 1;
   return 0;
 }
 
@@ -295,27 +316,13 @@ int rg_frontier_expand(rg_frontier* f, const rg_graph* g, int64_t* counts_host, 
   RG_CHECK(f->level >= 0, "rg_frontier_expand: call rg_frontier_reset first");
   RG_CHECK(g->n_ent == f->n_ent, "rg_frontier_expand: graph has %d entities, frontier %d", g->n_ent, f->n_ent);
   hipStream_t s = (hipStream_t)stream;
-  const uint32_t* oldT = f->bitsT[f->tcur];
-  uint32_t* newT = f->bitsT[f->tcur ^ 1];
-  int WL = 1;
-  while (WL < f->BW && WL < 64) WL <<= 1;
-  RG_HIP(hipMemsetAsync(&f->counters[2], 0, 8, s));
-  hipLaunchKernelGGL(count_edges_kernel, dim3(rg::ceil_div((int64_t)f->n_ent * f->BW, 256)), dim3(256), 0, s, g->out_ptr,
-                     oldT, f->n_ent, f->BW, (unsigned long long*)&f->counters[2]);
-  RG_LAUNCH_CHECK();
-  RG_HIP(hipMemsetAsync(newT, 0, (size_t)f->n_ent * f->BW * 4, s));
-  hipLaunchKernelGGL(hop_or_kernel, dim3(rg::ceil_div(g->in_vr.n, 4)), dim3(256), 0, s, g->in_vr.rows, g->in_vr.n, g->in_hr,
-                     oldT, newT, f->BW, WL);
-  RG_LAUNCH_CHECK();
   const int64_t n_old = f->n_nodes[f->level % f->n_levels];
-  f->tcur ^= 1;
-  f->level += 1;
-  if (build_level(f, s)) return 1;
+  if (enqueue_expand(f, g, s)) return 1;
   RG_HIP(hipMemcpyAsync(f->counts_pinned, f->counters, 32, hipMemcpyDeviceToHost, s));
   RG_HIP(hipStreamSynchronize(s));
   const int32_t* c32 = (const int32_t*)f->counts_pinned;
   RG_CHECK(c32[1] == 0, "rg_frontier_expand: a start node had batch or entity id out of range");
-  RG_CHECK(f->level != 1 || c32[4] == n_old, "rg_frontier_expand: %lld start nodes given but %d distinct (duplicates?)",
+  RG_CHECK(f->level != 1 || n_old < 0 || c32[4] == n_old, "rg_frontier_expand: %lld start nodes given but %d distinct (duplicates?)",
            (long long)n_old, c32[4]);
   const int64_t n_new = c32[0];
   int64_t e;
@@ -323,6 +330,36 @@ int rg_frontier_expand(rg_frontier* f, const rg_graph* g, int64_t* counts_host, 
   f->n_nodes[f->level % f->n_levels] = n_new;
   f->n_edges = e;
   if (counts_host) { counts_host[0] = n_new; counts_host[1] = e; counts_host[2] = n_old; counts_host[3] = f->level; }
+  return 0;
+}
+
+int rg_frontier_expand_async(rg_frontier* f, const rg_graph* g, void* stream) {
+  RG_CHECK(f && g, "rg_frontier_expand_async: NULL argument");
+  RG_CHECK(f->level >= 0, "rg_frontier_expand_async: call rg_frontier_reset first");
+  RG_CHECK(g->n_ent == f->n_ent, "rg_frontier_expand_async: graph has %d entities, frontier %d", g->n_ent, f->n_ent);
+  RG_CHECK(f->level + 1 < RG_MAX_LEVELS, "rg_frontier_expand_async: at most %d levels", RG_MAX_LEVELS - 1);
+  if (enqueue_expand(f, g, (hipStream_t)stream)) return 1;
+  f->n_nodes[f->level % f->n_levels] = -1;      // unknown on the host: the layer calls take their n as a capacity hint
+  f->n_edges = -1;
+  return 0;
+}
+
+const int32_t* rg_frontier_count_ptr(const rg_frontier* f) { return f ? f->counters : nullptr; }
+
+int rg_frontier_level_counts(const rg_frontier* f, int64_t* counts_host, void* stream) {
+  RG_CHECK(f && counts_host, "rg_frontier_level_counts: NULL argument");
+  RG_CHECK(f->level >= 0 && f->level < RG_MAX_LEVELS, "rg_frontier_level_counts: level %d", f->level);
+  hipStream_t s = (hipStream_t)stream;
+  int32_t* host = (int32_t*)f->counts_pinned + 16;      // pinned: [0..7] is rg_frontier_expand's, snapshots behind it
+  RG_HIP(hipMemcpyAsync(host, &f->counters[64], sizeof(int32_t) * 8 * (f->level + 1), hipMemcpyDeviceToHost, s));
+  RG_HIP(hipStreamSynchronize(s));
+  counts_host[0] = f->n_nodes[0]; counts_host[1] = 0;
+  for (int l = 1; l <= f->level; ++l) {
+    const int32_t* c = host + 8 * l;
+    RG_CHECK(c[1] == 0, "rg_frontier_level_counts: a start node had batch or entity id out of range");
+    counts_host[2 * l] = c[0];
+    memcpy(&counts_host[2 * l + 1], &c[2], 8);
+  }
   return 0;
 }
 
@@ -354,7 +391,7 @@ int rg_frontier_edges(const rg_frontier* f, const rg_graph* g, int32_t level, co
   int32_t* scan_scr = (int32_t*)((char*)scratch + rg::align_up((size_t)(n_new + 1) * 4, 256));
   int32_t* total = scan_scr;          // first element; scan scratch proper starts after
   const int2* bm_old = f->bm_of(level - 1);
-  if (n_new == 0) { RG_HIP(hipMemsetAsync(row_ptr, 0, 4, s)); return 0; }
+  if (n_new == 0) return rg::zero_async(row_ptr, 4, s);
   hipLaunchKernelGGL(edge_count_kernel, dim3(rg::ceil_div(n_new, 256)), dim3(256), 0, s, nodes_new, n_new, g->in_ptr,
                      g->in_hr, bm_old, f->W, deg);
   RG_LAUNCH_CHECK();

@@ -99,6 +99,39 @@ __global__ __launch_bounds__(SCAN_T) void scan_apply_kernel(const uint32_t* in, 
   if (!offsets && total && threadIdx.x == 0) *total = tot;
 }
 
+__global__ void zero_words_kernel(uint32_t* __restrict__ p, int64_t n_words) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += stride) p[i] = 0u;
+}
+__global__ void zero_quads_kernel(uint4* __restrict__ p, int64_t n_quads) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_quads; i += stride) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+__global__ void copy_words_kernel(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, int n) {
+  if ((int)threadIdx.x < n) dst[threadIdx.x] = src[threadIdx.x];
+}
+
+int zero_async(void* p, size_t bytes, hipStream_t s) {
+  if (bytes == 0) return 0;
+  RG_CHECK(((uintptr_t)p & 3) == 0 && (bytes & 3) == 0, "zero_async: unaligned fill (%p, %zu B)", p, bytes);
+  if (((uintptr_t)p & 15) == 0 && (bytes & 15) == 0 && bytes >= 4096) {
+    const int64_t n = (int64_t)(bytes / 16);
+    hipLaunchKernelGGL(zero_quads_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(n, 256), 4096)), dim3(256), 0, s, (uint4*)p, n);
+  } else {
+    const int64_t n = (int64_t)(bytes / 4);
+    hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(n, 256), 4096)), dim3(256), 0, s, (uint32_t*)p, n);
+  }
+  RG_LAUNCH_CHECK();
+  return 0;
+}
+
+int copy_words_async(void* dst, const void* src, int n_words, hipStream_t s) {
+  RG_CHECK(n_words > 0 && n_words <= 256, "copy_words_async: %d words", n_words);
+  hipLaunchKernelGGL(copy_words_kernel, dim3(1), dim3(256), 0, s, (uint32_t*)dst, (const uint32_t*)src, n_words);
+  RG_LAUNCH_CHECK();
+  return 0;
+}
+
 size_t scan_scratch_elems(int64_t n) {
   size_t tot = 0;
   while (n > SCAN_TILE) {
@@ -111,7 +144,7 @@ size_t scan_scratch_elems(int64_t n) {
 int scan_exclusive(const uint32_t* in, int32_t* out, int64_t n, bool popc, int32_t* total_dev,
                    int32_t* scratch, hipStream_t s) {
   if (n <= 0) {
-    if (total_dev) RG_HIP(hipMemsetAsync(total_dev, 0, sizeof(int32_t), s));
+    if (total_dev && zero_async(total_dev, sizeof(int32_t), s)) return 1;
     return 0;
   }
   const int64_t nb = ceil_div(n, SCAN_TILE);

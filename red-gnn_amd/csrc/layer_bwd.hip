@@ -444,7 +444,7 @@ int launch_drel(const DrelArgs& A, hipStream_t s) {
   auto kern = drel_kernel<G, AP4>;
   if (lds > 64 * 1024) RG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int grid = rg::walk_grid(A.walk.n_items, BWD_BLOCK, G, true, lds <= 80 * 1024 ? 2 : 1, 1);
-  RG_HIP(hipMemsetAsync(A.walk.queues, 0, 8 * sizeof(int32_t), s));
+  if (rg::zero_async(A.walk.queues, 8 * sizeof(int32_t), s)) return 1;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(BWD_BLOCK), lds, s, A);
   RG_LAUNCH_CHECK();
   return 0;
@@ -495,7 +495,7 @@ int launch3(const BwdArgs& A, size_t lds, int B, const rg_vrows& vr, const int2*
   if (lds > 64 * 1024) RG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int per_cu = lds <= 80 * 1024 ? 2 : 1;
   const int grid = rg::walk_grid(A.walk.n_items, BWD_BLOCK, G, DENSE, per_cu, 1);
-  RG_HIP(hipMemsetAsync(A.walk.queues, 0, 8 * sizeof(int32_t), s));
+  if (rg::zero_async(A.walk.queues, 8 * sizeof(int32_t), s)) return 1;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(BWD_BLOCK), lds, s, A);
   RG_LAUNCH_CHECK();
   if (vr.n_split > 0) {

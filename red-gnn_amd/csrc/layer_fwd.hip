@@ -22,6 +22,7 @@ extern "C" int rg_layer_fwd(const rg_frontier* f, const rg_graph* g, int32_t lev
   A.w_alpha = w_alpha; A.b_alpha = b_alpha;
   A.agg = (float4*)agg_out; A.partial = (float4*)scratch;
   // dense walk when at least a quarter of all (query, entity) pairs are visited; else filter 64 items per wave
+  // (after rg_frontier_expand_async n_new is the caller's estimate: it only picks the walk, both are exact)
   const bool dense = n_new * 4 >= (int64_t)f->B * f->n_ent;
   return rgfwd::dispatch<false>(A, ld / 4, ap / 4, f->B, g->in_vr, dense, rg::walk_kpg(g->n_fact, g->in_vr.n), (hipStream_t)stream);
 }

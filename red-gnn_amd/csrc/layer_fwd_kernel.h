@@ -232,7 +232,7 @@ int launch3(const FwdArgs& A, size_t lds, int B, const rg_vrows& vr, hipStream_t
   if (lds > 64 * 1024) RG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int per_cu = lds <= 53 * 1024 ? 3 : (lds <= 80 * 1024 ? 2 : 1);
   const int grid = rg::walk_grid(A.walk.n_items, BLOCK, G, DENSE, per_cu, KPG);
-  RG_HIP(hipMemsetAsync(A.walk.queues, 0, 8 * sizeof(int32_t), s));
+  if (rg::zero_async(A.walk.queues, 8 * sizeof(int32_t), s)) return 1;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds, s, A);
   RG_LAUNCH_CHECK();
   if (vr.n_split > 0) {
@@ -289,8 +289,10 @@ inline int fill_common(const char* who, const rg_frontier* f, const rg_graph* g,
   RG_CHECK(g->n_ent == f->n_ent, "%s: graph has %d entities, frontier %d", who, g->n_ent, f->n_ent);
   RG_CHECK(level >= 1 && level <= f->level && level > f->level - f->n_levels + 1, "%s: level %d not resident (current %d, %d kept)",
            who, level, f->level, f->n_levels);
-  RG_CHECK(n_new == f->n_nodes[level % f->n_levels], "%s: n_new=%lld but level %d has %lld nodes", who, (long long)n_new, level,
-           (long long)f->n_nodes[level % f->n_levels]);
+  // after rg_frontier_expand_async the host does not know the level's size: n_new is then only an estimate (> 0) that picks the
+  // walk, and agg_out must have room for any outcome (B * n_ent rows)
+  RG_CHECK(f->n_nodes[level % f->n_levels] < 0 || n_new == f->n_nodes[level % f->n_levels], "%s: n_new=%lld but level %d has %lld nodes",
+           who, (long long)n_new, level, (long long)f->n_nodes[level % f->n_levels]);
   RG_CHECK(d > 0 && ld >= d && ld % 4 == 0 && ld >= 16 && ld <= 256, "%s: d=%d ld=%d (need ld%%4==0, 16<=ld<=256)", who, d, ld);
   RG_CHECK(attn_dim > 0 && ap >= attn_dim && ap % 4 == 0, "%s: attn_dim=%d ap=%d", who, attn_dim, ap);
   RG_CHECK(g->in_vr.n_slots == 0 || (scratch && scratch_bytes >= need), "%s: scratch %zu B < required %zu B", who, scratch_bytes, need);

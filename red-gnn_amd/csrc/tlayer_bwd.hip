@@ -301,7 +301,7 @@ int launch2(const TBwdArgs& A, int B, const rg_vrows& vr, const int2* bm_old, hi
   auto kern = tlayer_bwd_kernel<G, AP4, DENSE>;
   if (lds > 64 * 1024) RG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int grid = rg::walk_grid(A.walk.n_items, TB_BLOCK, G, DENSE, lds <= 80 * 1024 ? 2 : 1, 1);
-  RG_HIP(hipMemsetAsync(A.walk.queues, 0, 8 * sizeof(int32_t), s));
+  if (rg::zero_async(A.walk.queues, 8 * sizeof(int32_t), s)) return 1;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(TB_BLOCK), lds, s, A);
   RG_LAUNCH_CHECK();
   if (vr.n_split > 0) {

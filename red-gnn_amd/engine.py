@@ -121,6 +121,27 @@ class Frontier:
         self.n_new, self.n_edges, self.n_old, self.level = (int(self._counts[i]) for i in range(4))
         return self.n_new, self.n_edges, self.n_old
 
+    def expand_async(self, graph):
+        """One hop with no read-back (rg_frontier_expand_async): nothing synchronises; the sizes stay on the device
+        (count_ptr, level_counts) and self.n_new / n_old / n_edges are unknown (-1) until level_counts() is called."""
+        _lib.check(_lib.lib().rg_frontier_expand_async(self.handle, graph.handle, _lib.stream_ptr()))
+        self.level += 1
+        self.n_new = self.n_old = self.n_edges = -1
+
+    def count_ptr(self):
+        """Device address of the newest level's node count (int32), for dense_fwd_dev."""
+        return C.c_void_p(_lib.lib().rg_frontier_count_ptr(self.handle))
+
+    def level_counts(self):
+        """[(N_l, E_l) for l = 0..level] read back from the device (synchronises the stream)."""
+        buf = (C.c_int64 * 32)()
+        _lib.check(_lib.lib().rg_frontier_level_counts(self.handle, buf, _lib.stream_ptr()))
+        return [(int(buf[2 * l]), int(buf[2 * l + 1])) for l in range(self.level + 1)]
+
+    def nodes_into(self, nodes, prev):
+        """rg_frontier_nodes into caller-owned buffers of capacity batch * n_ent rows (no size needed on the host)."""
+        _lib.check(_lib.lib().rg_frontier_nodes(self.handle, _lib.ptr(nodes), _lib.ptr(prev), None, _lib.stream_ptr()))
+
     def nodes(self, want_prev=True, want_old_new=True):
         """(nodes int32 [n_new,2] sorted, prev_idx int32 [n_new] or None, old_nodes_new_idx int32 [n_old] or None)."""
         nodes = torch.empty((self.n_new, 2), dtype=torch.int32, device=self.device)
@@ -189,6 +210,15 @@ def layer_fwd(frontier, graph, level, nodes_new, hidden, rela, d, a_s, a_r, a_q,
         ev[1].record()
         KERNEL_EVENTS.append((ev[0], ev[1], frontier.n_edges, n_new))
     return agg
+
+
+def layer_fwd_into(frontier, graph, level, n_hint, hidden, rela, d, a_s, a_r, a_q, w_alpha, b_alpha, attn_dim, agg, scratch):
+    """rg_layer_fwd after expand_async: agg has room for batch * n_ent rows, n_hint (> 0) only picks the walk."""
+    ld, ap = hidden.shape[1], a_s.shape[1]
+    _lib.check(_lib.lib().rg_layer_fwd(frontier.handle, graph.handle, level, max(int(n_hint), 1),
+                                       _lib.ptr(hidden), _lib.ptr(rela), d, ld, _lib.ptr(a_s), _lib.ptr(a_r),
+                                       _lib.ptr(a_q), ap, _lib.ptr(w_alpha), _lib.ptr(b_alpha), attn_dim,
+                                       _lib.ptr(agg), _lib.ptr(scratch), scratch.numel(), _lib.stream_ptr()))
 
 
 def tlayer_fwd(frontier, graph, level, n_new, q_time, hidden_dir, rela_dir, time_dir, d, a_s, a_r, a_q, w_alpha, b_alpha, attn_dim):
@@ -298,6 +328,20 @@ def dense_fwd(agg, hidden_prev, prev_idx, d, W_h, act, gate, Ws_next=None, attn_
         ev[1].record()
         DENSE_EVENTS.append((ev[0], ev[1], n))
     return hidden, a_s
+
+
+def dense_fwd_dev(n_cap, count_ptr, agg, hidden_prev, prev_idx, d, W_h, act, gate, hidden_out, Ws_next=None, attn_dim=0, ap=0,
+                  a_s_out=None, W_final=None, nodes=None, n_ent=0, scores_all=None):
+    """rg_dense_fwd_dev: the fused dense epilogue with the row count read on the device (buffers of capacity n_cap)."""
+    ld = agg.shape[1]
+    c = lambda t: None if t is None else t.detach().contiguous()
+    W_h, w_ih, w_hh, b_ih, b_hh = c(W_h), c(gate.weight_ih_l0), c(gate.weight_hh_l0), c(gate.bias_ih_l0), c(gate.bias_hh_l0)
+    Ws_next, W_final = c(Ws_next), c(W_final)
+    _lib.check(_lib.lib().rg_dense_fwd_dev(n_cap, count_ptr, d, ld, _lib.ptr(agg), _lib.ptr(hidden_prev), _lib.ptr(prev_idx),
+                                           _lib.ptr(W_h), {"idd": 0, "relu": 1, "tanh": 2}[act], _lib.ptr(w_ih), _lib.ptr(w_hh),
+                                           _lib.ptr(b_ih), _lib.ptr(b_hh), _lib.ptr(Ws_next), attn_dim, ap, _lib.ptr(a_s_out),
+                                           _lib.ptr(W_final), _lib.ptr(nodes), n_ent, _lib.ptr(scores_all), _lib.ptr(hidden_out),
+                                           _lib.stream_ptr()))
 
 
 def rank(scores, ans_ptr, ans_idx, filt_ptr, filt_idx):

@@ -15,6 +15,8 @@ What is different inside (nothing is different outside):
     of the node-row GEMMs issued in row-chunked batched form (``tall_linear``: a [m,n] = G^T X product over millions of
     rows otherwise lands on a handful of workgroups).
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -143,6 +145,97 @@ class GNNLayer(nn.Module):
         return self.act(tall_linear(agg, self.W_h.weight))                       # models.py:41
 
 
+class _GraphedInference:
+    """One inference forward of RED_GNN_trans for a fixed (graph, batch size) as a captured HIP graph.
+
+    The eager path reads the new frontier's size back once per hop (to size its buffers) and issues ~15 launches per layer
+    from Python; at the reference's evaluation batch sizes (n_tbatch = 50) that host work is the whole step.  Here every buffer
+    has the capacity of the full (query, entity) grid, the hop runs without the read-back (rg_frontier_expand_async), the
+    kernels take the level's size from device memory (rg_dense_fwd_dev) or do not need it (bitmap walk), and the sequence is
+    captured once and replayed: one graph launch per batch, nothing synchronises."""
+
+    MAX_BYTES = 24 << 30
+
+    def __init__(self, model, graph, n, device, hints):
+        self.model, self.graph, self.n, self.hints = model, graph, n, hints
+        d, a = model.hidden_dim, model.attn_dim
+        self.ld, self.ap = max(16, _pad4(d)), _pad4(a)
+        n_ent = graph.n_ent
+        cap = self.cap = n * n_ent
+        f32 = dict(dtype=torch.float32, device=device)
+        self.q_sub = torch.zeros(n, dtype=torch.int32, device=device)
+        self.q_rel = torch.zeros(n, dtype=torch.int64, device=device)
+        self.fr = engine.Frontier(n_ent, n, 2, device)
+        self.nodes = torch.empty((cap, 2), dtype=torch.int32, device=device)
+        self.prev = torch.empty(cap, dtype=torch.int32, device=device)
+        self.agg = torch.empty((cap, self.ld), **f32)
+        self.hid = [torch.empty((cap, self.ld), **f32) for _ in range(2)]
+        self.a_s = [torch.empty((cap, self.ap), **f32) for _ in range(2)]
+        self.scores = torch.empty(cap, **f32)
+        nbytes = _lib_scratch_bytes(self.fr, graph, self.ld)
+        self.scratch = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+        self.key_ptr = model.W_final.weight.data_ptr()
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side), torch.no_grad():       # a warm-up pass on the capture conditions, then the capture itself
+            self._enqueue()
+        torch.cuda.current_stream(device).wait_stream(side)
+        self.cuda_graph = None
+        if os.environ.get("RG_NO_CAPTURE") != "1":           # debugging aid: enqueue the same sequence eagerly on every call
+            self.cuda_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.cuda_graph), torch.no_grad():
+                self._enqueue()
+
+    @staticmethod
+    def bytes_needed(n, n_ent, ld, ap):
+        return n * n_ent * (4 * (3 * ld + 2 * ap + 1) + 12)
+
+    def _enqueue(self):
+        m, fr, graph, n = self.model, self.fr, self.graph, self.n
+        d, a, ld, ap = m.hidden_dim, m.attn_dim, self.ld, self.ap
+        fr.reset(self.q_sub)
+        hidden, a_s = self.hid[1], self.a_s[1]
+        hidden[:n].zero_()                                    # hidden == 0 at layer 0 (models.py:74)
+        a_s[:n].zero_()
+        self.scores.zero_()                                   # models.py:87
+        pad_rows = lambda w: F.pad(w, (0, 0, 0, ap - a)) if ap != a else w
+        for i in range(m.n_layer):
+            layer = m.gnn_layers[i]
+            fr.expand_async(graph)
+            fr.nodes_into(self.nodes, self.prev)
+            rela = layer.rela_embed.weight
+            a_r = F.linear(rela, pad_rows(layer.Wr_attn.weight)).contiguous()
+            a_q = F.linear(rela[self.q_rel], pad_rows(layer.Wqr_attn.weight), F.pad(layer.Wqr_attn.bias, (0, ap - a))).contiguous()
+            rela_p = (F.pad(rela, (0, ld - d)) if ld != d else rela).contiguous()
+            engine.layer_fwd_into(fr, graph, fr.level, self.hints[i], hidden, rela_p, d, a_s, a_r, a_q,
+                                  layer.w_alpha.weight.reshape(-1).contiguous(), layer.w_alpha.bias, a, self.agg, self.scratch)
+            last = i + 1 == m.n_layer
+            out_h, out_a = self.hid[i % 2], self.a_s[i % 2]
+            engine.dense_fwd_dev(self.cap, fr.count_ptr(), self.agg, hidden, self.prev, d, layer.W_h.weight, m.act_name, m.gate, out_h,
+                                 Ws_next=None if last else m.gnn_layers[i + 1].Ws_attn.weight, attn_dim=a, ap=ap,
+                                 a_s_out=None if last else out_a, W_final=m.W_final.weight if last else None,
+                                 nodes=self.nodes, n_ent=graph.n_ent, scores_all=self.scores)
+            hidden, a_s = out_h, out_a
+
+    def run(self, q_sub, q_rel):
+        self.q_sub.copy_(q_sub, non_blocking=True)
+        self.q_rel.copy_(q_rel, non_blocking=True)
+        if self.cuda_graph is not None:
+            self.cuda_graph.replay()
+        else:
+            self._enqueue()
+        return self.scores.view(self.n, self.graph.n_ent).clone()     # the static buffer is overwritten by the next replay
+
+    def stats(self):
+        counts = self.fr.level_counts()                       # one read-back, only when somebody asks
+        return dict(n_edges=[e for (_, e) in counts[1:]], n_nodes=counts[-1][0])
+
+
+def _lib_scratch_bytes(frontier, graph, ld):
+    from . import _lib
+    return _lib.lib().rg_layer_fwd_scratch_bytes(frontier.handle, graph.handle, ld)
+
+
 class RED_GNN_trans(nn.Module):
     def __init__(self, params, loader):
         super().__init__()
@@ -157,8 +250,21 @@ class RED_GNN_trans(nn.Module):
         self.W_final = nn.Linear(self.hidden_dim, 1, bias=False)
         self.gate = nn.GRU(self.hidden_dim, self.hidden_dim)     # parameters only; the single step runs as gru_cell
         self._frontiers = {}
-        self.last_stats = None
+        self._last_stats = None
         self.fused_dense = True      # inference: W_h + GRU + projections + readout in one MFMA kernel (rg_dense_fwd)
+        self.use_graphs = True       # inference: replay a captured HIP graph per (graph, batch size) from the third call on
+        self._graphed, self._seen, self._hints, self._pending_key = {}, {}, {}, None
+
+    @property
+    def last_stats(self):
+        """dict(n_edges=[E per layer], n_nodes=N of the last layer) of the latest forward (read back lazily after a graph replay)."""
+        if callable(self._last_stats):
+            self._last_stats = self._last_stats()
+        return self._last_stats
+
+    @last_stats.setter
+    def last_stats(self, value):
+        self._last_stats = value
 
     def _frontier(self, n_ent, batch, n_levels, device):
         key = (n_ent, batch, n_levels, str(device))
@@ -178,9 +284,14 @@ class RED_GNN_trans(nn.Module):
         q_rel = torch.as_tensor(np.asarray(rels), dtype=torch.int64).to(device)
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         n_ent = graph.n_ent                     # the inductive setting switches graphs (and n_ent) with the mode
+        fused = not need_grad and self.fused_dense and engine.dense_supported(self.hidden_dim, self.attn_dim)
+        if fused and self.use_graphs and trace is None and engine.KERNEL_EVENTS is None and engine.DENSE_EVENTS is None:
+            out = self._forward_graphed(graph, q_sub, q_rel, n, device)
+            if out is not None:
+                return out
         fr = self._frontier(n_ent, n, self.n_layer + 1 if need_grad else 2, device)
         fr.reset(q_sub)
-        if not need_grad and self.fused_dense and engine.dense_supported(self.hidden_dim, self.attn_dim):
+        if fused:
             return self._forward_inference(fr, graph, q_sub, q_rel, n, device, trace)
 
         d = self.hidden_dim
@@ -208,6 +319,30 @@ class RED_GNN_trans(nn.Module):
         self.last_stats = dict(n_edges=n_edges, n_nodes=int(nodes_old.shape[0]))
         return scores_all.view(n, n_ent)
 
+    def _forward_graphed(self, graph, q_sub, q_rel, n, device):
+        """Replay (or, on the third call with the same graph and batch size, capture) the forward as a HIP graph.
+        Returns None when this call should run eagerly: the first two calls of a shape (the eager run also provides the
+        per-hop sizes that pick the kernels' walks), or shapes whose full-grid buffers would be too large."""
+        key = (id(graph), n, str(device))
+        g = self._graphed.get(key)
+        if g is not None and g.key_ptr != self.W_final.weight.data_ptr():        # parameters were re-allocated (.to(), ...)
+            g = None
+            self._graphed.pop(key)
+        if g is None:
+            ld, ap = max(16, _pad4(self.hidden_dim)), _pad4(self.attn_dim)
+            seen = self._seen.get(key, 0)
+            self._seen[key] = seen + 1
+            if seen < 2 or _GraphedInference.bytes_needed(n, graph.n_ent, ld, ap) > _GraphedInference.MAX_BYTES:
+                self._pending_key = key          # the eager run that follows records its per-hop sizes under this key
+                return None
+            hints = self._hints.get(key) or [n * graph.n_ent] * self.n_layer
+            if len(self._graphed) >= 3:
+                self._graphed.clear()
+            g = self._graphed[key] = _GraphedInference(self, graph, n, device, hints)
+        scores = g.run(q_sub, q_rel)
+        self._last_stats = g.stats
+        return scores
+
     def _forward_inference(self, fr, graph, q_sub, q_rel, n, device, trace):
         """The same forward with no autograd graph: per layer one expansion, one fused message-passing
         kernel and one fused dense kernel; hidden / a_s never leave their padded device layout."""
@@ -217,12 +352,13 @@ class RED_GNN_trans(nn.Module):
         hidden = torch.zeros((n, ld), device=device)
         a_s = torch.zeros((n, ap), device=device)                     # hidden == 0 at layer 0 (models.py:74)
         scores_all = torch.zeros(n * n_ent, device=device)           # models.py:87
-        n_edges = []
+        n_edges, sizes = [], []
         nodes = None
         for i in range(self.n_layer):
             n_new, n_e, _ = fr.expand(graph)
             nodes, prev_idx, old_new = fr.nodes(want_prev=True, want_old_new=trace is not None)
             n_edges.append(n_e)
+            sizes.append(n_new)
             layer = self.gnn_layers[i]
             agg = layer.aggregate_nograd(q_rel, hidden, a_s, fr, graph, fr.level, nodes)
             last = i + 1 == self.n_layer
@@ -233,6 +369,11 @@ class RED_GNN_trans(nn.Module):
             if trace is not None:
                 trace.append(dict(nodes=nodes, old_nodes_new_idx=old_new, n_edges=n_e, hidden=hidden[:, :d]))
         self.last_stats = dict(n_edges=n_edges, n_nodes=int(nodes.shape[0]))
+        if getattr(self, "_pending_key", None) is not None:
+            if len(self._hints) > 16:
+                self._hints.clear()
+            self._hints[self._pending_key] = sizes
+            self._pending_key = None
         return scores_all.view(n, n_ent)
 
 

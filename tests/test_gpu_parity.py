@@ -666,3 +666,37 @@ def test_nan_scrub_replaces_only_nans_and_consumes_one_draw_per_parameter():
     for p, b in zip(params, before):
         keep = ~torch.isnan(b)
         assert torch.equal(p.data[keep], b[keep])
+
+
+def test_graph_replay_matches_eager_forward():
+    """Inference as a captured HIP graph (rg_frontier_expand_async + rg_dense_fwd_dev, buffers at full-grid capacity): from the
+    third call of a shape on the forward is a graph replay; scores, stats and ranks equal the eager path's bit for bit, for
+    changing queries and after a parameter update."""
+    from red_gnn_amd.load_data import DataLoader
+    from red_gnn_amd.models import RED_GNN_trans
+    from red_gnn_amd.synthetic import make_synthetic_kg
+    kg = make_synthetic_kg(500, 9, 6000, seed=8)
+    loader = DataLoader(ids=dict(n_ent=kg.n_ent, n_rel=kg.n_rel, facts=kg.facts, train=kg.train, valid=kg.valid, test=kg.test), verbose=False)
+
+    class P:
+        n_layer, hidden_dim, attn_dim, n_rel, act, dropout = 3, 48, 5, kg.n_rel, "relu", 0.1
+
+    torch.manual_seed(3)
+    model = RED_GNN_trans(P, loader).cuda().eval()
+    rng = np.random.default_rng(0)
+    B = 37
+    with torch.no_grad():
+        for it in range(6):
+            q = kg.test[rng.integers(0, len(kg.test), B)]
+            model.use_graphs = True
+            s_g = model(q[:, 0], q[:, 1], mode="test")
+            st_g = dict(model.last_stats)
+            model.use_graphs = False
+            s_e = model(q[:, 0], q[:, 1], mode="test")
+            st_e = dict(model.last_stats)
+            assert torch.equal(s_g, s_e), it
+            assert st_g == st_e, (it, st_g, st_e)
+            if it == 3:                                       # parameters change in place between replays (training between evals)
+                for p_ in model.parameters():
+                    p_.data.mul_(1.01)
+    assert len(model._graphed) == 1
