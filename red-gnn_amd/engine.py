@@ -212,6 +212,10 @@ def layer_fwd(frontier, graph, level, nodes_new, hidden, rela, d, a_s, a_r, a_q,
     return agg
 
 
+def layer_fwd_scratch_bytes(frontier, graph, ld):
+    return _lib.lib().rg_layer_fwd_scratch_bytes(frontier.handle, graph.handle, ld)
+
+
 def layer_fwd_into(frontier, graph, level, n_hint, hidden, rela, d, a_s, a_r, a_q, w_alpha, b_alpha, attn_dim, agg, scratch):
     """rg_layer_fwd after expand_async: agg has room for batch * n_ent rows, n_hint (> 0) only picks the walk."""
     ld, ap = hidden.shape[1], a_s.shape[1]

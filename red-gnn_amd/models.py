@@ -172,7 +172,7 @@ class _GraphedInference:
         self.hid = [torch.empty((cap, self.ld), **f32) for _ in range(2)]
         self.a_s = [torch.empty((cap, self.ap), **f32) for _ in range(2)]
         self.scores = torch.empty(cap, **f32)
-        nbytes = _lib_scratch_bytes(self.fr, graph, self.ld)
+        nbytes = engine.layer_fwd_scratch_bytes(self.fr, graph, self.ld)
         self.scratch = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
         self.key_ptr = model.W_final.weight.data_ptr()
         side = torch.cuda.Stream(device=device)
@@ -229,11 +229,6 @@ class _GraphedInference:
     def stats(self):
         counts = self.fr.level_counts()                       # one read-back, only when somebody asks
         return dict(n_edges=[e for (_, e) in counts[1:]], n_nodes=counts[-1][0])
-
-
-def _lib_scratch_bytes(frontier, graph, ld):
-    from . import _lib
-    return _lib.lib().rg_layer_fwd_scratch_bytes(frontier.handle, graph.handle, ld)
 
 
 class RED_GNN_trans(nn.Module):
