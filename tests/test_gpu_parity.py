@@ -700,3 +700,57 @@ def test_graph_replay_matches_eager_forward():
                 for p_ in model.parameters():
                     p_.data.mul_(1.01)
     assert len(model._graphed) == 1
+
+
+@pytest.mark.parametrize("d", [64, 128])
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 127, 128, 129, 1000, 4099])
+def test_dense_kernel_row_count_edges(d, n):
+    """rg_dense_fwd / rg_dense_fwd_dev straight through the engine on row counts around the 16-node tile and the 128-node round
+    of the streamed d=128 kernel, with and without old nodes, middle layer (a_s out) and last layer (readout), against torch."""
+    from red_gnn_amd import engine
+    torch.manual_seed(n * 7 + d)
+    a, ap, n_old, n_ent = 5, 8, max(1, n // 3), 50
+    dev = "cuda"
+    agg = torch.randn(n, d, device=dev)
+    hprev = torch.randn(n_old, d, device=dev)
+    prev = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    sel = torch.randperm(n, device=dev)[:min(n_old, n)]
+    prev[sel] = torch.arange(sel.numel(), dtype=torch.int32, device=dev)
+    gate = torch.nn.GRU(d, d).to(dev)
+    W_h, Ws, W_final = torch.randn(d, d, device=dev) / d ** 0.5, torch.randn(a, d, device=dev) / d ** 0.5, torch.randn(1, d, device=dev)
+    nodes = torch.stack([torch.arange(n, device=dev, dtype=torch.int32) // n_ent, torch.arange(n, device=dev, dtype=torch.int32) % n_ent], 1).contiguous()
+    n_q = (n + n_ent - 1) // n_ent
+
+    def reference(prev_idx):
+        x = torch.tanh(agg @ W_h.t())
+        h0 = torch.zeros(n, d, device=dev)
+        if prev_idx is not None:
+            m = prev_idx >= 0
+            h0[m] = hprev[prev_idx[m].long()]
+        h = torch.gru_cell(x, h0, gate.weight_ih_l0, gate.weight_hh_l0, gate.bias_ih_l0, gate.bias_hh_l0)
+        return h, h @ Ws.t(), (h @ W_final.t()).reshape(-1)
+
+    with torch.no_grad():
+        for prev_idx in (prev, None):
+            h_ref, as_ref, sc_ref = reference(prev_idx)
+            h1, a1 = engine.dense_fwd(agg, hprev, prev_idx, d, W_h, "tanh", gate, Ws_next=Ws, attn_dim=a, ap=ap)
+            np.testing.assert_allclose(h1.cpu().numpy(), h_ref.cpu().numpy(), rtol=RTOL, atol=ATOL_H)
+            np.testing.assert_allclose(a1[:, :a].cpu().numpy(), as_ref.cpu().numpy(), rtol=RTOL, atol=ATOL_H)
+            scores = torch.zeros(n_q * n_ent, device=dev)
+            h2, _ = engine.dense_fwd(agg, hprev, prev_idx, d, W_h, "tanh", gate, W_final=W_final, nodes=nodes, n_ent=n_ent, scores_all=scores)
+            assert torch.equal(h1, h2)
+            np.testing.assert_allclose(scores[:n].cpu().numpy(), sc_ref.cpu().numpy(), rtol=RTOL, atol=ATOL_H)
+            assert not scores[n:].any()
+        # the device-count form on buffers with spare capacity: rows beyond the count stay untouched
+        cap = n + 300
+        agg_c = torch.cat([agg, torch.full((300, d), float("nan"), device=dev)])
+        prev_c = torch.cat([prev, torch.full((300,), 5, dtype=torch.int32, device=dev)])
+        out = torch.full((cap, d), -7.0, device=dev)
+        a_out = torch.full((cap, ap), -7.0, device=dev)
+        count = torch.tensor([n, 0, 0, 0], dtype=torch.int32, device=dev)
+        import ctypes
+        engine.dense_fwd_dev(cap, ctypes.c_void_p(count.data_ptr()), agg_c, hprev, prev_c, d, W_h, "tanh", gate, out, Ws_next=Ws, attn_dim=a,
+                             ap=ap, a_s_out=a_out)
+        h_ref, as_ref, _ = reference(prev)
+        np.testing.assert_allclose(out[:n].cpu().numpy(), h_ref.cpu().numpy(), rtol=RTOL, atol=ATOL_H)
+        assert bool((out[n:] == -7.0).all()) and bool((a_out[n:] == -7.0).all())
