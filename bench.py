@@ -122,6 +122,8 @@ def main():
     ap.add_argument("--config", default="C2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--family-eval", action="store_true", help="also time BaseModel.evaluate on the real family graph (n_tbatch=50, graph replay); "
+                    "off by default so that a rocprofv3 run of the default command sees the C2 step's kernels only")
     ap.add_argument("--graphs", action="store_true", help="replay the forward as a captured HIP graph (no per-kernel HIP events, so no roofline object)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group even at world size 1 (exercises the RCCL path on one GPU)")
     args = ap.parse_args()
@@ -209,7 +211,7 @@ def main():
         dt, edges = float(tmax[0]), float(tsum[1])
     total_edges = float(edges)
 
-    family = family_eval(dist, world, engine)      # second half of the metric's name: filtered-MRR evaluation of the family graph
+    family = family_eval(dist, world, engine) if args.family_eval else None      # second half of the metric's name
 
     if rank == 0:
         # dominant kernel: layer_fwd_kernel (HIP events recorded around every launch of the timed steps)
