@@ -88,6 +88,14 @@ struct rg_graph {
   int32_t* rel_ptr = nullptr;
   int2* rel_ht = nullptr;
   rg_vrows rel_vr;
+  // temporal graphs: time id of every CSR-by-relation entry, and a CSR by time id (rows = time ids; time_ht = {head, tail},
+  // time_rel = relation): the temporal backward's table gradients are summed per 128-edge segment of one relation / one
+  // time id (one row add per segment instead of 2*d float atomics per edge)
+  int32_t* rel_tm = nullptr;
+  int32_t* time_ptr = nullptr;
+  int2* time_ht = nullptr;
+  int32_t* time_rel = nullptr;
+  rg_vrows time_vr;
 };
 
 // Frontier state, all inside the caller's workspace.

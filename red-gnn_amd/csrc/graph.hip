@@ -276,13 +276,39 @@ static int build_graph(int32_t n_ent, int32_t n_rel, int32_t n_rela_rows, const 
     for (int64_t i = 0; i < n_fact; ++i) rel_ptr[R[i] + 1]++;
     for (int32_t r = 0; r < n_rela_rows; ++r) rel_ptr[r + 1] += rel_ptr[r];
     std::vector<int2> rel_ht(n_fact);
+    std::vector<int32_t> rel_tm(TIME ? n_fact : 0);
     std::vector<int32_t> pr(rel_ptr.begin(), rel_ptr.end() - 1);
-    for (int64_t i = 0; i < n_fact; ++i) rel_ht[pr[R[i]]++] = make_int2(H[i], T[i]);
+    for (int64_t i = 0; i < n_fact; ++i) {
+      const int32_t q = pr[R[i]]++;
+      rel_ht[q] = make_int2(H[i], T[i]);
+      if (TIME) rel_tm[q] = (*TIME)[i];
+    }
     RG_HIP_G(hipMalloc(&g->rel_ptr, (n_rela_rows + 1) * sizeof(int32_t)));
     RG_HIP_G(hipMalloc(&g->rel_ht, std::max<int64_t>(n_fact, 1) * sizeof(int2)));
     RG_HIP_G(hipMemcpy(g->rel_ptr, rel_ptr.data(), (n_rela_rows + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
     RG_HIP_G(hipMemcpy(g->rel_ht, rel_ht.data(), n_fact * sizeof(int2), hipMemcpyHostToDevice));
     if (build_vrows(rel_ptr, n_rela_rows, &g->rel_vr)) return fail();
+    if (TIME) {
+      RG_HIP_G(hipMalloc(&g->rel_tm, std::max<int64_t>(n_fact, 1) * sizeof(int32_t)));
+      RG_HIP_G(hipMemcpy(g->rel_tm, rel_tm.data(), n_fact * sizeof(int32_t), hipMemcpyHostToDevice));
+      std::vector<int32_t> time_ptr(n_time + 1, 0);
+      for (int64_t i = 0; i < n_fact; ++i) time_ptr[(*TIME)[i] + 1]++;
+      for (int32_t t = 0; t < n_time; ++t) time_ptr[t + 1] += time_ptr[t];
+      std::vector<int2> time_ht(n_fact);
+      std::vector<int32_t> time_rel(n_fact), pt(time_ptr.begin(), time_ptr.end() - 1);
+      for (int64_t i = 0; i < n_fact; ++i) {
+        const int32_t q = pt[(*TIME)[i]]++;
+        time_ht[q] = make_int2(H[i], T[i]);
+        time_rel[q] = R[i];
+      }
+      RG_HIP_G(hipMalloc(&g->time_ptr, (n_time + 1) * sizeof(int32_t)));
+      RG_HIP_G(hipMalloc(&g->time_ht, std::max<int64_t>(n_fact, 1) * sizeof(int2)));
+      RG_HIP_G(hipMalloc(&g->time_rel, std::max<int64_t>(n_fact, 1) * sizeof(int32_t)));
+      RG_HIP_G(hipMemcpy(g->time_ptr, time_ptr.data(), (n_time + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+      RG_HIP_G(hipMemcpy(g->time_ht, time_ht.data(), n_fact * sizeof(int2), hipMemcpyHostToDevice));
+      RG_HIP_G(hipMemcpy(g->time_rel, time_rel.data(), n_fact * sizeof(int32_t), hipMemcpyHostToDevice));
+      if (build_vrows(time_ptr, n_time, &g->time_vr)) return fail();
+    }
   }
 #undef RG_HIP_G
   if (build_vrows(in_ptr, n_ent, &g->in_vr) || build_vrows(out_ptr, n_ent, &g->out_vr)) return fail();
@@ -341,7 +367,11 @@ int rg_graph_destroy(rg_graph* g) {
   if (g->out_time) (void)hipFree(g->out_time);
   if (g->rel_ptr) (void)hipFree(g->rel_ptr);
   if (g->rel_ht) (void)hipFree(g->rel_ht);
-  for (rg_vrows* v : {&g->in_vr, &g->out_vr, &g->rel_vr}) {
+  if (g->rel_tm) (void)hipFree(g->rel_tm);
+  if (g->time_ptr) (void)hipFree(g->time_ptr);
+  if (g->time_ht) (void)hipFree(g->time_ht);
+  if (g->time_rel) (void)hipFree(g->time_rel);
+  for (rg_vrows* v : {&g->in_vr, &g->out_vr, &g->rel_vr, &g->time_vr}) {
     if (v->rows) (void)hipFree(v->rows);
     if (v->split) (void)hipFree(v->split);
   }

@@ -3,7 +3,9 @@
 // Same source-pull structure as layer_bwd.hip (walk over CSR-by-head segments of the previous frontier's nodes), with
 //   m_e = hidden_dir[3 s + dir] + rela_dir[dir * n_rela_rows + r] + time_dir[dir * n_time + |dt|],   dt = time(e) - q_time[b]
 //   d hidden_dir[3 s + dir] += alpha G[o]      (three register accumulators per source, one store per row)
-//   d rela_dir / d time_dir rows += alpha G[o] (global float atomics: training batches of this model are small)
+//   d rela_dir / d time_dir rows += alpha G[o] (separate key-major passes, tkey_kernel: items are 128-edge segments of one
+//                                               relation / one time id, so a whole segment lands in at most three rows / one row
+//                                               and is added once; per-edge float atomics on a 2.5 k-row table cost 20x the forward)
 //   g_alpha = <G[o], m_e>  ->  d a_s[s], d a_r[r], d w   exactly as in the static kernel.
 // The direction linears and the attention's three blocks are differentiated by the caller (dense GEMMs).
 #include "aq_sum.h"
@@ -188,12 +190,6 @@ __global__ __launch_bounds__(TB_BLOCK, 4) void tlayer_bwd_kernel(TBwdArgs A) {
             acc[dd].x = fmaf(m, ag.x, acc[dd].x); acc[dd].y = fmaf(m, ag.y, acc[dd].y);
             acc[dd].z = fmaf(m, ag.z, acc[dd].z); acc[dd].w = fmaf(m, ag.w, acc[dd].w);
           }
-          if (al != 0.f && row_lane) {
-            float* gr = A.g_rela_dir + ((int64_t)__float_as_int(tp[u].y) * A.ld4 + lane_g) * 4;
-            atomicAdd(gr + 0, ag.x); atomicAdd(gr + 1, ag.y); atomicAdd(gr + 2, ag.z); atomicAdd(gr + 3, ag.w);
-            float* gt = A.g_time_dir + ((int64_t)(__float_as_int(tp[u].w) >> 2) * A.ld4 + lane_g) * 4;
-            atomicAdd(gt + 0, ag.x); atomicAdd(gt + 1, ag.y); atomicAdd(gt + 2, ag.z); atomicAdd(gt + 3, ag.w);
-          }
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -293,6 +289,188 @@ __global__ void tbwd_combine_kernel(const int4* __restrict__ split, int n_split,
   else g_as[(int64_t)s * ap4 + (c - cols_h)] = acc;
 }
 
+// ---- table gradients, key-major -------------------------------------------------------------------------------------------
+// BY_TIME = false: items = (query, segment of relation r's edge list); an edge's direction follows from its time id, so the
+//                  segment's alpha*G sums go to up to three rows  dir * n_rela_rows + r  of g_rela_dir.
+// BY_TIME = true : items = (query, segment of time id tau's edge list); dt = tau - q_time[b] is the same for the whole segment,
+//                  which therefore lands in the single row  dir * n_time + |dt|  of g_time_dir.
+struct TKeyArgs {
+  rg::WalkArgs walk;          // vrows = CSR-by-relation / CSR-by-time segments; always live
+  const int2* ht;             // {head, tail} per entry
+  const int32_t* aux;         // BY_TIME ? relation : time id, per entry
+  const int32_t* q_time;
+  const int2* bm_old;
+  const int2* bm_new;
+  int W;
+  const float4* a_s;
+  const float4* a_r;
+  const float4* a_q;
+  const float* w_alpha;
+  const float* b_alpha;
+  int attn_dim, n_rela_rows, n_time, ld4;
+  const float4* grad_agg;
+  float* g_table;             // g_rela_dir or g_time_dir
+};
+
+template <int G, int AP4, bool BY_TIME>
+__global__ __launch_bounds__(TB_BLOCK, 4) void tkey_kernel(TKeyArgs A) {
+  extern __shared__ float4 lds[];
+  constexpr int BLOCK = TB_BLOCK;
+  const int nr = A.n_rela_rows;
+  float4* stage = lds;                // [BLOCK] {o, alpha, dir}
+  float4* ar_l = stage + BLOCK;       // [nr][AP4]
+  float4* w_l = ar_l + nr * AP4;      // [AP4]
+  for (int i = threadIdx.x; i < nr * AP4; i += BLOCK) ar_l[i] = A.a_r[i];
+  if (threadIdx.x < AP4) {
+    float w[4];
+    for (int k = 0; k < 4; ++k) {
+      const int j = threadIdx.x * 4 + k;
+      w[k] = j < A.attn_dim ? A.w_alpha[j] : 0.f;
+    }
+    w_l[threadIdx.x] = make_float4(w[0], w[1], w[2], w[3]);
+  }
+  __syncthreads();
+  const float b_alpha = A.b_alpha[0];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int lane_g = lane & (G - 1), gi_w = lane / G;
+  float4* my_stage = stage + wv * 64 + gi_w * G;
+  const int gshift = lane & ~(G - 1);
+  const unsigned long long gmask = G == 64 ? ~0ull : ((1ull << G) - 1ull);
+  const bool row_lane = lane_g < A.ld4;
+  const int lane_c = row_lane ? lane_g : A.ld4 - 1;
+
+  rg::walk_items<G, true, 1, BLOCK, true>(A.walk, nullptr, [&](const int4& R, bool live) {
+    const int beg = R.x, end = R.x + rg::walk_len(R), b = R.z, key = R.w;
+    const int2* old_row = A.bm_old + (int64_t)b * A.W;
+    const int2* new_row = A.bm_new + (int64_t)b * A.W;
+    const int qt = A.q_time[b];
+    float4 aq[AP4];
+#pragma unroll
+    for (int k = 0; k < AP4; ++k) aq[k] = A.a_q[(int64_t)b * AP4 + k];
+    float4 acc[BY_TIME ? 1 : 3];
+#pragma unroll
+    for (int dd = 0; dd < (BY_TIME ? 1 : 3); ++dd) acc[dd] = f4zero();
+    unsigned seen = 0u;      // directions with at least one edge (BY_TIME: bit 0)
+    for (int c0 = beg; c0 < end; c0 += G) {
+      const int c = c0 + lane_g;
+      bool valid = c < end;
+      int o = 0, dir = 0;
+      float alpha = 0.f;
+      if (valid) {
+        const int2 ht = A.ht[c];
+        const int2 wp = old_row[ht.x >> 5];
+        const uint32_t word = (uint32_t)wp.x, bit = ht.x & 31;
+        valid = (word >> bit) & 1u;
+        if (valid) {
+          const int s = wp.y + __popc(word & ((1u << bit) - 1u));
+          const int2 wn = new_row[ht.y >> 5];
+          o = wn.y + __popc((uint32_t)wn.x & ((1u << (ht.y & 31)) - 1u));
+          const int other = A.aux[c];
+          const int r = BY_TIME ? other : key;
+          if constexpr (!BY_TIME) { const int dt = other - qt; dir = dt > 0 ? 2 : (dt == 0 ? 1 : 0); }
+          float z = b_alpha;
+#pragma unroll
+          for (int k = 0; k < AP4; ++k) {
+            const float4 as = A.a_s[(int64_t)s * AP4 + k];
+            const float4 ar = ar_l[r * AP4 + k];
+            const float4 w = w_l[k];
+            z = fmaf(w.x, fmaxf(as.x + ar.x + aq[k].x, 0.f), z);
+            z = fmaf(w.y, fmaxf(as.y + ar.y + aq[k].y, 0.f), z);
+            z = fmaf(w.z, fmaxf(as.z + ar.z + aq[k].z, 0.f), z);
+            z = fmaf(w.w, fmaxf(as.w + ar.w + aq[k].w, 0.f), z);
+          }
+          alpha = __builtin_amdgcn_rcpf(1.0f + __expf(-z));
+        }
+      }
+      const unsigned long long m = (__ballot(valid) >> gshift) & gmask;
+      const int cnt = __popcll(m);
+      const int pos = __popcll(m & ((1ull << lane_g) - 1ull));
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      if (lane_g >= cnt) my_stage[lane_g] = f4zero();
+      if (valid) my_stage[pos] = make_float4(__int_as_float(o), alpha, __int_as_float(dir), 0.f);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      for (int k = 0; k < cnt; k += 4) {
+        float4 tp[4], gv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) tp[u] = my_stage[k + u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) gv[u] = A.grad_agg[(int64_t)__float_as_int(tp[u].x) * A.ld4 + lane_c];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float al = tp[u].y;
+          if constexpr (BY_TIME) {
+            acc[0].x = fmaf(al, gv[u].x, acc[0].x); acc[0].y = fmaf(al, gv[u].y, acc[0].y);
+            acc[0].z = fmaf(al, gv[u].z, acc[0].z); acc[0].w = fmaf(al, gv[u].w, acc[0].w);
+            if (k + u < cnt) seen |= 1u;
+          } else {
+            const int du = __float_as_int(tp[u].z);
+#pragma unroll
+            for (int dd = 0; dd < 3; ++dd) {
+              const float mk = du == dd ? al : 0.f;
+              acc[dd].x = fmaf(mk, gv[u].x, acc[dd].x); acc[dd].y = fmaf(mk, gv[u].y, acc[dd].y);
+              acc[dd].z = fmaf(mk, gv[u].z, acc[dd].z); acc[dd].w = fmaf(mk, gv[u].w, acc[dd].w);
+            }
+            if (k + u < cnt) seen |= 1u << du;
+          }
+        }
+      }
+    }
+    if (live && row_lane) {
+      if constexpr (BY_TIME) {
+        if (seen) {
+          const int dt = key - qt;
+          const int dir = dt > 0 ? 2 : (dt == 0 ? 1 : 0);
+          float* gr = A.g_table + ((int64_t)(dir * A.n_time + (dt < 0 ? -dt : dt)) * A.ld4 + lane_g) * 4;
+          atomicAdd(gr + 0, acc[0].x); atomicAdd(gr + 1, acc[0].y); atomicAdd(gr + 2, acc[0].z); atomicAdd(gr + 3, acc[0].w);
+        }
+      } else {
+#pragma unroll
+        for (int dd = 0; dd < 3; ++dd)
+          if (seen & (1u << dd)) {
+            float* gr = A.g_table + ((int64_t)(dd * nr + key) * A.ld4 + lane_g) * 4;
+            atomicAdd(gr + 0, acc[dd].x); atomicAdd(gr + 1, acc[dd].y); atomicAdd(gr + 2, acc[dd].z); atomicAdd(gr + 3, acc[dd].w);
+          }
+      }
+    }
+  });
+}
+
+template <int G, int AP4, bool BY_TIME>
+int launch_tkey(const TKeyArgs& A, hipStream_t s) {
+  const size_t lds = (size_t)(TB_BLOCK + A.n_rela_rows * AP4 + AP4) * sizeof(float4);
+  RG_CHECK(lds <= 160 * 1024, "rg_tlayer_bwd: attention table needs %zu B of LDS (> 160 KiB)", lds);
+  auto kern = tkey_kernel<G, AP4, BY_TIME>;
+  if (lds > 64 * 1024) RG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int grid = rg::walk_grid(A.walk.n_items, TB_BLOCK, G, true, lds <= 80 * 1024 ? 2 : 1, 1);
+  if (rg::zero_async(A.walk.queues, 8 * sizeof(int32_t), s)) return 1;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(TB_BLOCK), lds, s, A);
+  RG_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int G, bool BY_TIME>
+int launch_tkey_ap(const TKeyArgs& A, int ap4, hipStream_t s) {
+  switch (ap4) {
+    case 1: return launch_tkey<G, 1, BY_TIME>(A, s);
+    case 2: return launch_tkey<G, 2, BY_TIME>(A, s);
+    case 3: return launch_tkey<G, 3, BY_TIME>(A, s);
+    case 4: return launch_tkey<G, 4, BY_TIME>(A, s);
+    case 8: return launch_tkey<G, 8, BY_TIME>(A, s);
+    default: rg::set_error("rg_tlayer_bwd: padded attention dim %d not in {4,8,12,16,32}", ap4 * 4); return 1;
+  }
+}
+
+template <bool BY_TIME>
+int launch_tkey_g(const TKeyArgs& A, int ld4, int ap4, hipStream_t s) {
+  if (ld4 <= 4) return launch_tkey_ap<4, BY_TIME>(A, ap4, s);
+  if (ld4 <= 8) return launch_tkey_ap<8, BY_TIME>(A, ap4, s);
+  if (ld4 <= 16) return launch_tkey_ap<16, BY_TIME>(A, ap4, s);
+  if (ld4 <= 32) return launch_tkey_ap<32, BY_TIME>(A, ap4, s);
+  return launch_tkey_ap<64, BY_TIME>(A, ap4, s);
+}
+
 template <int G, int AP4, bool DENSE>
 int launch2(const TBwdArgs& A, int B, const rg_vrows& vr, const int2* bm_old, hipStream_t s) {
   size_t lds = (size_t)(TB_BLOCK + 2 * A.n_rela_rows * AP4 + AP4 + (TB_BLOCK / 64) * (AP4 + 1)) * sizeof(float4);
@@ -339,7 +517,7 @@ extern "C" int rg_tlayer_bwd(const rg_frontier* f, const rg_graph* g, int32_t le
   RG_CHECK(f && g && q_time && hidden_dir && rela_dir && time_dir && a_s && a_r && a_q && w_alpha && b_alpha && grad_agg &&
                grad_hidden_dir && grad_rela_dir && grad_time_dir && grad_a_s && grad_a_r && grad_w_alpha,
            "rg_tlayer_bwd: NULL argument");
-  RG_CHECK(g->out_time && g->n_time > 0, "rg_tlayer_bwd: the graph has no timestamps (build it with rg_tgraph_create)");
+  RG_CHECK(g->out_time && g->rel_tm && g->time_ht && g->n_time > 0, "rg_tlayer_bwd: the graph has no timestamps (build it with rg_tgraph_create)");
   RG_CHECK(g->n_ent == f->n_ent, "rg_tlayer_bwd: graph has %d entities, frontier %d", g->n_ent, f->n_ent);
   RG_CHECK(level >= 1 && level <= f->level && level > f->level - f->n_levels + 1,
            "rg_tlayer_bwd: level %d not resident (current %d, %d kept)", level, f->level, f->n_levels);
@@ -382,5 +560,20 @@ extern "C" int rg_tlayer_bwd(const rg_frontier* f, const rg_graph* g, int32_t le
   else if (ld4 <= 32) rc = launch_ap<32>(A, ap / 4, f->B, g->out_vr, bm_old, dense, s);
   else rc = launch_ap<64>(A, ap / 4, f->B, g->out_vr, bm_old, dense, s);
   if (rc) return rc;
-  return grad_a_q ? rg::launch_aq_sum(bm_old, f->W, f->B, f->n_ent, n_old, grad_a_s, ap, grad_a_q, s) : 0;
+  if (grad_a_q && rg::launch_aq_sum(bm_old, f->W, f->B, f->n_ent, n_old, grad_a_s, ap, grad_a_q, s)) return 1;
+  // table gradients, key-major (see tkey_kernel)
+  TKeyArgs K;
+  K.q_time = q_time; K.bm_old = bm_old; K.bm_new = f->bm_of(level); K.W = f->W;
+  K.a_s = (const float4*)a_s; K.a_r = (const float4*)a_r; K.a_q = (const float4*)a_q;
+  K.w_alpha = w_alpha; K.b_alpha = b_alpha; K.attn_dim = attn_dim; K.n_rela_rows = g->n_rela_rows; K.n_time = g->n_time; K.ld4 = ld4;
+  K.grad_agg = (const float4*)grad_agg;
+  K.walk.n_slots = 0; K.walk.bm_test = nullptr; K.walk.W = f->W; K.walk.queues = f->counters + 16;
+  K.walk.n_items = (int64_t)f->B * g->rel_vr.n; K.walk.n_vrows = g->rel_vr.n; K.walk.vrows = g->rel_vr.rows;
+  RG_CHECK(K.walk.n_items / 8 + ((int64_t)1 << 26) < ((int64_t)1 << 31), "rg_tlayer_bwd: relation work space too large for 32-bit queue tickets");
+  K.ht = g->rel_ht; K.aux = g->rel_tm; K.g_table = grad_rela_dir;
+  if (launch_tkey_g<false>(K, ld4, ap / 4, s)) return 1;
+  K.walk.n_items = (int64_t)f->B * g->time_vr.n; K.walk.n_vrows = g->time_vr.n; K.walk.vrows = g->time_vr.rows;
+  RG_CHECK(K.walk.n_items / 8 + ((int64_t)1 << 26) < ((int64_t)1 << 31), "rg_tlayer_bwd: time work space too large for 32-bit queue tickets");
+  K.ht = g->time_ht; K.aux = g->time_rel; K.g_table = grad_time_dir;
+  return launch_tkey_g<true>(K, ld4, ap / 4, s);
 }

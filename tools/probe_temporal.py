@@ -38,3 +38,24 @@ for it in range(4):
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     e = sum(model.last_stats["n_edges"])
     print("C5 temporal B=%d it%d: %.2f ms, edges %.3g per hop %s -> %.3g edges/s" % (B, it, dt * 1e3, e, model.last_stats["n_edges"], e / dt))
+
+# one training step of the same model (mode='train': the batch's quadruples leave the graph; main.py's loss)
+import torch.nn.functional as F
+model.train()
+opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+batch["example_idx"] = np.arange(B)
+tails = torch.as_tensor(quads[:B, 2], device="cuda")
+for it in range(5):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    g = __import__("red_gnn_amd.engine", fromlist=["x"]).TemporalGraph(n_ent, n_rel + 1, n_time + 1, np.delete(model.quads, batch["example_idx"], axis=0))
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    opt.zero_grad()
+    s = model(batch, mode="train")
+    loss = F.nll_loss(torch.log(F.softmax(s, dim=1) + 1e-12), tails)
+    torch.cuda.synchronize(); t2 = time.perf_counter()
+    loss.backward()
+    torch.cuda.synchronize(); t3 = time.perf_counter()
+    opt.step()
+    torch.cuda.synchronize(); t4 = time.perf_counter()
+    print("C5 temporal train B=%d it%d: graph rebuild alone %.2f ms | fwd (incl. its own rebuild) %.2f ms  bwd %.2f ms  opt %.2f ms  loss %.4f"
+          % (B, it, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3, loss.item()))
