@@ -48,6 +48,11 @@ int rg_graph_create(int32_t n_ent, int32_t n_rel, const int32_t* triples_host, i
  * holds the identity rows with the sentinel timestamp); n_rela_rows = rows of the relation tables. */
 int rg_tgraph_create(int32_t n_ent, int32_t n_rela_rows, int32_t n_time, const int32_t* quads_host, int64_t n,
                      rg_graph** out);
+/* The same graph without the rows listed in exclude_rows_host (row indices into quads, duplicates allowed): the training
+ * mode of T_RED_GNN.forward, `dataset = np.delete(self.dataset, batch['example_idx'], axis=0)` (model_cuda.py:103-104),
+ * without a host copy of the array per batch. */
+int rg_tgraph_create_excluding(int32_t n_ent, int32_t n_rela_rows, int32_t n_time, const int32_t* quads_host, int64_t n,
+                               const int64_t* exclude_rows_host, int64_t n_exclude, rg_graph** out);
 int rg_graph_destroy(rg_graph* g);
 int64_t rg_graph_n_fact(const rg_graph* g);      /* rows incl. inverse + identity (load_data.py:80) */
 /* copy the device CSR back (tests): ptr arrays have n_ent+1 entries, pair arrays 2*n_fact. */

@@ -65,6 +65,7 @@ struct rg_vrows {
 };
 
 struct rg_graph {
+  void* arena = nullptr;     // the one device allocation all arrays below are slices of
   int32_t n_ent = 0, n_rel = 0;
   int32_t n_rela_rows = 0;   // rows of the relation table: 2*n_rel+1 (static), n_rel_total+1 (temporal)
   int32_t n_time = 0;        // temporal graphs: number of time ids (0 = static graph)

@@ -175,9 +175,11 @@ int scan_exclusive(const uint32_t* in, int32_t* out, int64_t n, bool popc, int32
 
 }  // namespace rg
 
-// cut CSR rows into length-sorted virtual rows (see common.h) and upload them
-static int build_vrows(const std::vector<int32_t>& ptr, int32_t n_ent, rg_vrows* out) {
-  std::vector<int4> rows, split;
+// cut CSR rows into length-sorted virtual rows (see common.h); the arrays are uploaded with the rest of the graph
+struct HostVrows { std::vector<int4> rows, split; };
+static void host_vrows(const std::vector<int32_t>& ptr, int32_t n_ent, HostVrows* h, rg_vrows* out) {
+  std::vector<int4>& rows = h->rows;
+  std::vector<int4>& split = h->split;
   int32_t slots = 0;
   for (int32_t e = 0; e < n_ent; ++e) {
     const int32_t beg = ptr[e], len = ptr[e + 1] - ptr[e];
@@ -195,12 +197,22 @@ static int build_vrows(const std::vector<int32_t>& ptr, int32_t n_ent, rg_vrows*
   }
   std::stable_sort(rows.begin(), rows.end(), [](const int4& a, const int4& b) { return a.z > b.z; });
   out->n = (int32_t)rows.size(); out->n_split = (int32_t)split.size(); out->n_slots = slots;
-  RG_HIP(hipMalloc(&out->rows, std::max<size_t>(rows.size(), 1) * sizeof(int4)));
-  RG_HIP(hipMalloc(&out->split, std::max<size_t>(split.size(), 1) * sizeof(int4)));
-  RG_HIP(hipMemcpy(out->rows, rows.data(), rows.size() * sizeof(int4), hipMemcpyHostToDevice));
-  if (!split.empty()) RG_HIP(hipMemcpy(out->split, split.data(), split.size() * sizeof(int4), hipMemcpyHostToDevice));
-  return 0;
 }
+
+// One device allocation per graph: every array is a slice of it, filled by one host-to-device copy.  (Two dozen hipMalloc /
+// hipMemcpy pairs - and as many synchronising hipFree calls on destruction - were most of the cost of building a graph, which
+// temporal training does once per batch.)
+struct Arena {
+  struct Item { void** field; const void* src; size_t bytes, off; };
+  std::vector<Item> items;
+  size_t total = 0;
+  template <typename P, typename V>
+  void add(P** field, const V& v) {
+    const size_t bytes = v.size() * sizeof(typename V::value_type);
+    items.push_back({(void**)field, (const void*)v.data(), bytes, total});
+    total += rg::align_up(std::max<size_t>(bytes, 16), 256);
+  }
+};
 
 extern "C" {
 
@@ -225,18 +237,22 @@ static int build_graph(int32_t n_ent, int32_t n_rel, int32_t n_rela_rows, const 
   std::vector<int32_t> in_time(TIME ? n_fact : 0), out_time(TIME ? n_fact : 0);
   {
     std::vector<int32_t> po(out_ptr.begin(), out_ptr.end() - 1), pi(in_ptr.begin(), in_ptr.end() - 1);
-    std::vector<int32_t> out_fact(n_fact);
     for (int64_t i = 0; i < n_fact; ++i) {  // stable: fact-row order inside each CSR row
-      out_fact[po[H[i]]++] = (int32_t)i;
       const int32_t q = pi[T[i]]++;
       in_hr[q] = make_int2(H[i], R[i]);
       if (TIME) in_time[q] = (*TIME)[i];
     }
     // CSR-by-head rows ordered by relation (then fact order): the backward kernel then sees runs of equal relation
-    // and adds one partial sum per run (not per edge) to the privatised relation gradient
-    for (int32_t e = 0; e < n_ent; ++e)
-      std::stable_sort(out_fact.begin() + out_ptr[e], out_fact.begin() + out_ptr[e + 1],
-                       [&](int32_t a, int32_t b) { return R[a] < R[b]; });
+    // and adds one partial sum per run (not per edge) to the privatised relation gradient.  Two stable counting
+    // passes (by relation, then by head) instead of a comparison sort per row.
+    std::vector<int32_t> by_rel(n_fact), out_fact(n_fact);
+    {
+      std::vector<int32_t> pr(n_rela_rows + 1, 0);
+      for (int64_t i = 0; i < n_fact; ++i) pr[R[i] + 1]++;
+      for (int32_t r = 0; r < n_rela_rows; ++r) pr[r + 1] += pr[r];
+      for (int64_t i = 0; i < n_fact; ++i) by_rel[pr[R[i]]++] = (int32_t)i;
+    }
+    for (int64_t k = 0; k < n_fact; ++k) out_fact[po[H[by_rel[k]]]++] = by_rel[k];
     for (int64_t j = 0; j < n_fact; ++j) {
       const int32_t i = out_fact[j];
       out_rt[j] = make_int2(R[i], T[i]);
@@ -246,72 +262,68 @@ static int build_graph(int32_t n_ent, int32_t n_rel, int32_t n_rela_rows, const 
   rg_graph* g = new rg_graph();
   g->n_ent = n_ent; g->n_rel = n_rel; g->n_rela_rows = n_rela_rows; g->n_time = n_time;
   g->n_fact = n_fact; g->max_in_deg = max_in; g->max_out_deg = max_out;
-  auto fail = [&]() { rg_graph_destroy(g); return 1; };
-#define RG_HIP_G(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { rg::set_error("%s failed: %s", #expr, hipGetErrorString(e_)); return fail(); } } while (0)
-  RG_HIP_G(hipMalloc(&g->out_ptr, (n_ent + 1) * sizeof(int32_t)));
-  RG_HIP_G(hipMalloc(&g->in_ptr, (n_ent + 1) * sizeof(int32_t)));
-  RG_HIP_G(hipMalloc(&g->out_rt, std::max<int64_t>(n_fact, 1) * sizeof(int2)));
-  RG_HIP_G(hipMalloc(&g->in_hr, std::max<int64_t>(n_fact, 1) * sizeof(int2)));
-  RG_HIP_G(hipMemcpy(g->out_ptr, out_ptr.data(), (n_ent + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
-  RG_HIP_G(hipMemcpy(g->in_ptr, in_ptr.data(), (n_ent + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
-  RG_HIP_G(hipMemcpy(g->out_rt, out_rt.data(), n_fact * sizeof(int2), hipMemcpyHostToDevice));
-  RG_HIP_G(hipMemcpy(g->in_hr, in_hr.data(), n_fact * sizeof(int2), hipMemcpyHostToDevice));
-  if (TIME) {
-    RG_HIP_G(hipMalloc(&g->in_time, std::max<int64_t>(n_fact, 1) * sizeof(int32_t)));
-    RG_HIP_G(hipMemcpy(g->in_time, in_time.data(), n_fact * sizeof(int32_t), hipMemcpyHostToDevice));
-    RG_HIP_G(hipMalloc(&g->out_time, std::max<int64_t>(n_fact, 1) * sizeof(int32_t)));
-    RG_HIP_G(hipMemcpy(g->out_time, out_time.data(), n_fact * sizeof(int32_t), hipMemcpyHostToDevice));
-  }
+  Arena A;
+  A.add(&g->out_ptr, out_ptr); A.add(&g->in_ptr, in_ptr); A.add(&g->out_rt, out_rt); A.add(&g->in_hr, in_hr);
+  if (TIME) { A.add(&g->in_time, in_time); A.add(&g->out_time, out_time); }
+  std::vector<uint32_t> in_pk, out_pk;
   if (n_ent <= (1 << 20) && n_rela_rows <= (1 << 12)) {
-    std::vector<uint32_t> pk(n_fact);
-    for (int64_t i = 0; i < n_fact; ++i) pk[i] = ((uint32_t)in_hr[i].y << 20) | (uint32_t)in_hr[i].x;
-    RG_HIP_G(hipMalloc(&g->in_pk, std::max<int64_t>(n_fact, 1) * sizeof(uint32_t)));
-    RG_HIP_G(hipMemcpy(g->in_pk, pk.data(), n_fact * sizeof(uint32_t), hipMemcpyHostToDevice));
-    for (int64_t i = 0; i < n_fact; ++i) pk[i] = ((uint32_t)out_rt[i].x << 20) | (uint32_t)out_rt[i].y;
-    RG_HIP_G(hipMalloc(&g->out_pk, std::max<int64_t>(n_fact, 1) * sizeof(uint32_t)));
-    RG_HIP_G(hipMemcpy(g->out_pk, pk.data(), n_fact * sizeof(uint32_t), hipMemcpyHostToDevice));
+    in_pk.resize(n_fact); out_pk.resize(n_fact);
+    for (int64_t i = 0; i < n_fact; ++i) {
+      in_pk[i] = ((uint32_t)in_hr[i].y << 20) | (uint32_t)in_hr[i].x;
+      out_pk[i] = ((uint32_t)out_rt[i].x << 20) | (uint32_t)out_rt[i].y;
+    }
+    A.add(&g->in_pk, in_pk); A.add(&g->out_pk, out_pk);
   }
+  // CSR by relation (and, for temporal graphs, by time id)
+  std::vector<int32_t> rel_ptr(n_rela_rows + 1, 0), rel_tm(TIME ? n_fact : 0);
+  std::vector<int2> rel_ht(n_fact);
+  for (int64_t i = 0; i < n_fact; ++i) rel_ptr[R[i] + 1]++;
+  for (int32_t r = 0; r < n_rela_rows; ++r) rel_ptr[r + 1] += rel_ptr[r];
   {
-    std::vector<int32_t> rel_ptr(n_rela_rows + 1, 0);
-    for (int64_t i = 0; i < n_fact; ++i) rel_ptr[R[i] + 1]++;
-    for (int32_t r = 0; r < n_rela_rows; ++r) rel_ptr[r + 1] += rel_ptr[r];
-    std::vector<int2> rel_ht(n_fact);
-    std::vector<int32_t> rel_tm(TIME ? n_fact : 0);
     std::vector<int32_t> pr(rel_ptr.begin(), rel_ptr.end() - 1);
     for (int64_t i = 0; i < n_fact; ++i) {
       const int32_t q = pr[R[i]]++;
       rel_ht[q] = make_int2(H[i], T[i]);
       if (TIME) rel_tm[q] = (*TIME)[i];
     }
-    RG_HIP_G(hipMalloc(&g->rel_ptr, (n_rela_rows + 1) * sizeof(int32_t)));
-    RG_HIP_G(hipMalloc(&g->rel_ht, std::max<int64_t>(n_fact, 1) * sizeof(int2)));
-    RG_HIP_G(hipMemcpy(g->rel_ptr, rel_ptr.data(), (n_rela_rows + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
-    RG_HIP_G(hipMemcpy(g->rel_ht, rel_ht.data(), n_fact * sizeof(int2), hipMemcpyHostToDevice));
-    if (build_vrows(rel_ptr, n_rela_rows, &g->rel_vr)) return fail();
-    if (TIME) {
-      RG_HIP_G(hipMalloc(&g->rel_tm, std::max<int64_t>(n_fact, 1) * sizeof(int32_t)));
-      RG_HIP_G(hipMemcpy(g->rel_tm, rel_tm.data(), n_fact * sizeof(int32_t), hipMemcpyHostToDevice));
-      std::vector<int32_t> time_ptr(n_time + 1, 0);
-      for (int64_t i = 0; i < n_fact; ++i) time_ptr[(*TIME)[i] + 1]++;
-      for (int32_t t = 0; t < n_time; ++t) time_ptr[t + 1] += time_ptr[t];
-      std::vector<int2> time_ht(n_fact);
-      std::vector<int32_t> time_rel(n_fact), pt(time_ptr.begin(), time_ptr.end() - 1);
-      for (int64_t i = 0; i < n_fact; ++i) {
-        const int32_t q = pt[(*TIME)[i]]++;
-        time_ht[q] = make_int2(H[i], T[i]);
-        time_rel[q] = R[i];
-      }
-      RG_HIP_G(hipMalloc(&g->time_ptr, (n_time + 1) * sizeof(int32_t)));
-      RG_HIP_G(hipMalloc(&g->time_ht, std::max<int64_t>(n_fact, 1) * sizeof(int2)));
-      RG_HIP_G(hipMalloc(&g->time_rel, std::max<int64_t>(n_fact, 1) * sizeof(int32_t)));
-      RG_HIP_G(hipMemcpy(g->time_ptr, time_ptr.data(), (n_time + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
-      RG_HIP_G(hipMemcpy(g->time_ht, time_ht.data(), n_fact * sizeof(int2), hipMemcpyHostToDevice));
-      RG_HIP_G(hipMemcpy(g->time_rel, time_rel.data(), n_fact * sizeof(int32_t), hipMemcpyHostToDevice));
-      if (build_vrows(time_ptr, n_time, &g->time_vr)) return fail();
-    }
   }
-#undef RG_HIP_G
-  if (build_vrows(in_ptr, n_ent, &g->in_vr) || build_vrows(out_ptr, n_ent, &g->out_vr)) return fail();
+  A.add(&g->rel_ptr, rel_ptr); A.add(&g->rel_ht, rel_ht);
+  std::vector<int32_t> time_ptr, time_rel;
+  std::vector<int2> time_ht;
+  HostVrows hv_in, hv_out, hv_rel, hv_time;
+  if (TIME) {
+    A.add(&g->rel_tm, rel_tm);
+    time_ptr.assign(n_time + 1, 0); time_rel.resize(n_fact); time_ht.resize(n_fact);
+    for (int64_t i = 0; i < n_fact; ++i) time_ptr[(*TIME)[i] + 1]++;
+    for (int32_t t = 0; t < n_time; ++t) time_ptr[t + 1] += time_ptr[t];
+    std::vector<int32_t> pt(time_ptr.begin(), time_ptr.end() - 1);
+    for (int64_t i = 0; i < n_fact; ++i) {
+      const int32_t q = pt[(*TIME)[i]]++;
+      time_ht[q] = make_int2(H[i], T[i]);
+      time_rel[q] = R[i];
+    }
+    A.add(&g->time_ptr, time_ptr); A.add(&g->time_ht, time_ht); A.add(&g->time_rel, time_rel);
+    host_vrows(time_ptr, n_time, &hv_time, &g->time_vr);
+    A.add(&g->time_vr.rows, hv_time.rows); A.add(&g->time_vr.split, hv_time.split);
+  }
+  host_vrows(in_ptr, n_ent, &hv_in, &g->in_vr);
+  host_vrows(out_ptr, n_ent, &hv_out, &g->out_vr);
+  host_vrows(rel_ptr, n_rela_rows, &hv_rel, &g->rel_vr);
+  A.add(&g->in_vr.rows, hv_in.rows); A.add(&g->in_vr.split, hv_in.split);
+  A.add(&g->out_vr.rows, hv_out.rows); A.add(&g->out_vr.split, hv_out.split);
+  A.add(&g->rel_vr.rows, hv_rel.rows); A.add(&g->rel_vr.split, hv_rel.split);
+
+  std::vector<char> staging(A.total);
+  for (const Arena::Item& it : A.items)
+    if (it.bytes) memcpy(staging.data() + it.off, it.src, it.bytes);
+  hipError_t e = hipMalloc(&g->arena, A.total);
+  if (e == hipSuccess) e = hipMemcpy(g->arena, staging.data(), A.total, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    rg::set_error("rg_graph_create: uploading %zu B failed: %s", A.total, hipGetErrorString(e));
+    rg_graph_destroy(g);
+    return 1;
+  }
+  for (const Arena::Item& it : A.items) *it.field = (char*)g->arena + it.off;
   *out = g;
   return 0;
 }
@@ -339,42 +351,42 @@ int rg_graph_create(int32_t n_ent, int32_t n_rel, const int32_t* triples, int64_
   return build_graph(n_ent, n_rel, 2 * n_rel + 1, H, R, T, nullptr, 0, out);
 }
 
-int rg_tgraph_create(int32_t n_ent, int32_t n_rela_rows, int32_t n_time, const int32_t* quads, int64_t n, rg_graph** out) {
-  RG_CHECK(out != nullptr, "rg_tgraph_create: out is NULL");
+static int tgraph_create(const char* who, int32_t n_ent, int32_t n_rela_rows, int32_t n_time, const int32_t* quads, int64_t n,
+                         const int64_t* exclude, int64_t n_exclude, rg_graph** out) {
+  RG_CHECK(out != nullptr, "%s: out is NULL", who);
   *out = nullptr;
-  RG_CHECK(n_ent > 0 && n_rela_rows > 0 && n_time > 0, "rg_tgraph_create: n_ent=%d n_rela_rows=%d n_time=%d must be positive",
-           n_ent, n_rela_rows, n_time);
-  RG_CHECK(n >= 0 && n < ((int64_t)1 << 31) && (n == 0 || quads != nullptr), "rg_tgraph_create: bad quadruples (n=%lld)", (long long)n);
-  std::vector<int32_t> H(n), R(n), T(n), TM(n);
+  RG_CHECK(n_ent > 0 && n_rela_rows > 0 && n_time > 0, "%s: n_ent=%d n_rela_rows=%d n_time=%d must be positive", who, n_ent, n_rela_rows, n_time);
+  RG_CHECK(n >= 0 && n < ((int64_t)1 << 31) && (n == 0 || quads != nullptr), "%s: bad quadruples (n=%lld)", who, (long long)n);
+  RG_CHECK(n_exclude >= 0 && (n_exclude == 0 || exclude != nullptr), "%s: bad exclusion list", who);
+  std::vector<char> drop(n_exclude ? n : 0, 0);
+  for (int64_t k = 0; k < n_exclude; ++k) {
+    RG_CHECK(exclude[k] >= 0 && exclude[k] < n, "%s: excluded row %lld out of range (n=%lld)", who, (long long)exclude[k], (long long)n);
+    drop[exclude[k]] = 1;
+  }
+  std::vector<int32_t> H, R, T, TM;
+  H.reserve(n); R.reserve(n); T.reserve(n); TM.reserve(n);
   for (int64_t i = 0; i < n; ++i) {
+    if (n_exclude && drop[i]) continue;
     const int32_t h = quads[4 * i], r = quads[4 * i + 1], t = quads[4 * i + 2], tm = quads[4 * i + 3];
     RG_CHECK(h >= 0 && h < n_ent && t >= 0 && t < n_ent && r >= 0 && r < n_rela_rows && tm >= 0 && tm < n_time,
-             "rg_tgraph_create: quadruple %lld = (%d,%d,%d,%d) out of range", (long long)i, h, r, t, tm);
-    H[i] = h; R[i] = r; T[i] = t; TM[i] = tm;
+             "%s: quadruple %lld = (%d,%d,%d,%d) out of range", who, (long long)i, h, r, t, tm);
+    H.push_back(h); R.push_back(r); T.push_back(t); TM.push_back(tm);
   }
   return build_graph(n_ent, 0, n_rela_rows, H, R, T, &TM, n_time, out);
 }
 
+int rg_tgraph_create(int32_t n_ent, int32_t n_rela_rows, int32_t n_time, const int32_t* quads, int64_t n, rg_graph** out) {
+  return tgraph_create("rg_tgraph_create", n_ent, n_rela_rows, n_time, quads, n, nullptr, 0, out);
+}
+
+int rg_tgraph_create_excluding(int32_t n_ent, int32_t n_rela_rows, int32_t n_time, const int32_t* quads, int64_t n,
+                               const int64_t* exclude_rows, int64_t n_exclude, rg_graph** out) {
+  return tgraph_create("rg_tgraph_create_excluding", n_ent, n_rela_rows, n_time, quads, n, exclude_rows, n_exclude, out);
+}
+
 int rg_graph_destroy(rg_graph* g) {
   if (!g) return 0;
-  if (g->out_ptr) (void)hipFree(g->out_ptr);
-  if (g->in_ptr) (void)hipFree(g->in_ptr);
-  if (g->out_rt) (void)hipFree(g->out_rt);
-  if (g->in_hr) (void)hipFree(g->in_hr);
-  if (g->in_pk) (void)hipFree(g->in_pk);
-  if (g->out_pk) (void)hipFree(g->out_pk);
-  if (g->in_time) (void)hipFree(g->in_time);
-  if (g->out_time) (void)hipFree(g->out_time);
-  if (g->rel_ptr) (void)hipFree(g->rel_ptr);
-  if (g->rel_ht) (void)hipFree(g->rel_ht);
-  if (g->rel_tm) (void)hipFree(g->rel_tm);
-  if (g->time_ptr) (void)hipFree(g->time_ptr);
-  if (g->time_ht) (void)hipFree(g->time_ht);
-  if (g->time_rel) (void)hipFree(g->time_rel);
-  for (rg_vrows* v : {&g->in_vr, &g->out_vr, &g->rel_vr, &g->time_vr}) {
-    if (v->rows) (void)hipFree(v->rows);
-    if (v->split) (void)hipFree(v->split);
-  }
+  if (g->arena) (void)hipFree(g->arena);      // every array of the graph is a slice of this one allocation
   delete g;
   return 0;
 }

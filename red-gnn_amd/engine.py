@@ -69,13 +69,20 @@ class TemporalGraph(Graph):
     """Device-resident quadruple graph (head, rel, tail, time id) of T-RED-GNN (Temporal/interpolation/graph.py:34-49),
     used as given: the reference's array already holds the identity rows with the sentinel timestamp."""
 
-    def __init__(self, n_ent, n_rela_rows, n_time, quads, device="cuda"):
+    def __init__(self, n_ent, n_rela_rows, n_time, quads, device="cuda", exclude=None):
+        """``exclude``: row indices of ``quads`` to leave out (the training mode's np.delete, done while the rows are read)."""
         self.device = _require_gpu(device)
-        q = np.ascontiguousarray(np.asarray(quads, dtype=np.int32).reshape(-1, 4))
+        q = quads if (isinstance(quads, np.ndarray) and quads.dtype == np.int32 and quads.flags.c_contiguous and quads.ndim == 2) \
+            else np.ascontiguousarray(np.asarray(quads, dtype=np.int32).reshape(-1, 4))
         self.n_ent, self.n_rel, self.n_rela_rows, self.n_time = int(n_ent), 0, int(n_rela_rows), int(n_time)
         h = C.c_void_p()
         with torch.cuda.device(self.device):
-            _lib.check(_lib.lib().rg_tgraph_create(self.n_ent, self.n_rela_rows, self.n_time, _lib.ptr(q), len(q), C.byref(h)))
+            if exclude is None:
+                _lib.check(_lib.lib().rg_tgraph_create(self.n_ent, self.n_rela_rows, self.n_time, _lib.ptr(q), len(q), C.byref(h)))
+            else:
+                ex = np.ascontiguousarray(np.asarray(exclude, dtype=np.int64).reshape(-1))
+                _lib.check(_lib.lib().rg_tgraph_create_excluding(self.n_ent, self.n_rela_rows, self.n_time, _lib.ptr(q), len(q),
+                                                                 _lib.ptr(ex), len(ex), C.byref(h)))
         self.handle = h
         self.n_fact = int(_lib.lib().rg_graph_n_fact(h))
 

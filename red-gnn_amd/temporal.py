@@ -77,8 +77,8 @@ class T_RED_GNN(nn.Module):
                 "softplus": F.softplus, "leaky_relu": F.leaky_relu}
         self.act = acts[params.act]
         self.dropout = nn.Dropout(getattr(params, "dropout", 0.0))               # model_cuda.py:58
-        self.quads = np.ascontiguousarray(np.asarray(params.graph, dtype=np.int64).reshape(-1, 4))
-        self.graph = engine.TemporalGraph(self.n_ent, self.n_rel + 1, self.n_time, params.graph,
+        self.quads = np.ascontiguousarray(np.asarray(params.graph, dtype=np.int32).reshape(-1, 4))
+        self.graph = engine.TemporalGraph(self.n_ent, self.n_rel + 1, self.n_time, self.quads,
                                           device=getattr(params, "device", "cuda"))
         self._frontiers = {}
         self.last_stats = None
@@ -107,7 +107,7 @@ class T_RED_GNN(nn.Module):
         graph = self.graph
         if mode == "train":     # model_cuda.py:103-104: the batch's own facts leave the graph
             drop = np.asarray(torch.as_tensor(batch["example_idx"]).cpu()).reshape(-1)
-            graph = engine.TemporalGraph(self.n_ent, self.n_rel + 1, self.n_time, np.delete(self.quads, drop, axis=0), device=device)
+            graph = engine.TemporalGraph(self.n_ent, self.n_rel + 1, self.n_time, self.quads, device=device, exclude=drop)
         with_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         fr = self._frontier(n, self.n_layer + 1 if with_grad else 2, device)
         fr.reset(heads)

@@ -47,7 +47,7 @@ batch["example_idx"] = np.arange(B)
 tails = torch.as_tensor(quads[:B, 2], device="cuda")
 for it in range(5):
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    g = __import__("red_gnn_amd.engine", fromlist=["x"]).TemporalGraph(n_ent, n_rel + 1, n_time + 1, np.delete(model.quads, batch["example_idx"], axis=0))
+    g = __import__("red_gnn_amd.engine", fromlist=["x"]).TemporalGraph(n_ent, n_rel + 1, n_time + 1, model.quads, exclude=batch["example_idx"])
     torch.cuda.synchronize(); t1 = time.perf_counter()
     opt.zero_grad()
     s = model(batch, mode="train")
