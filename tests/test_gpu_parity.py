@@ -754,3 +754,29 @@ def test_dense_kernel_row_count_edges(d, n):
         h_ref, as_ref, _ = reference(prev)
         np.testing.assert_allclose(out[:n].cpu().numpy(), h_ref.cpu().numpy(), rtol=RTOL, atol=ATOL_H)
         assert bool((out[n:] == -7.0).all()) and bool((a_out[n:] == -7.0).all())
+
+
+def test_graph_replay_inductive_switches_graphs():
+    """RED_GNN_induc evaluates on two graphs of different entity counts (mode 'transductive' / 'inductive'); the replayed
+    HIP graphs are keyed by the device graph and equal the eager path on both."""
+    from red_gnn_amd.inductive import DataLoader as IndLoader
+    from red_gnn_amd.models import RED_GNN_induc
+    ids = dict(U.load("ind_WN18RR_v1_ids.npz"))
+    loader = IndLoader(ids=ids, verbose=False)
+
+    class P:
+        n_layer, hidden_dim, attn_dim, n_rel, act, dropout = 3, 32, 5, loader.n_rel, "relu", 0.0
+
+    torch.manual_seed(5)
+    model = RED_GNN_induc(P, loader).cuda().eval()
+    rng = np.random.default_rng(2)
+    with torch.no_grad():
+        for it in range(5):
+            for mode, n_e in (("transductive", loader.n_ent), ("inductive", loader.n_ent_ind)):
+                subs, rels = rng.integers(0, n_e, 11), rng.integers(0, 2 * loader.n_rel, 11)
+                model.use_graphs = True
+                s_g = model(subs, rels, mode=mode)
+                model.use_graphs = False
+                s_e = model(subs, rels, mode=mode)
+                assert s_g.shape == (11, n_e) and torch.equal(s_g, s_e), (it, mode)
+    assert len(model._graphed) == 2
