@@ -115,26 +115,28 @@ __global__ void pack_kernel(const uint32_t* __restrict__ words, const int32_t* _
 }
 
 // ---- node list of the newest level + links to the previous level -----------------------------------
+// one (word, bit) pair per thread: the set bits of a word are consecutive node ids, so a wave's stores are contiguous
 __global__ void emit_nodes_kernel(const int2* __restrict__ bm_new, const int2* __restrict__ bm_old, int B, int W,
                                   int32_t* __restrict__ nodes, int32_t* __restrict__ prev_idx,
                                   int32_t* __restrict__ old_new) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i = t >> 5;
+  const int pos = (int)(t & 31);
   if (i >= (int64_t)B * W) return;
   const int2 nw = bm_new[i];
-  uint32_t bits = (uint32_t)nw.x;
-  if (!bits) return;
+  const uint32_t bits = (uint32_t)nw.x;
+  if (!((bits >> pos) & 1u)) return;
+  const int64_t idx = nw.y + __popc(bits & ((1u << pos) - 1u));
   const int b = (int)(i / W), w = (int)(i - (int64_t)b * W);
-  const int2 ow = bm_old ? bm_old[i] : make_int2(0, 0);
-  int idx = nw.y;
-  while (bits) {
-    const int pos = __ffs(bits) - 1;
-    bits &= bits - 1;
-    if (nodes) { nodes[2 * (int64_t)idx] = b; nodes[2 * (int64_t)idx + 1] = w * 32 + pos; }
+  if (nodes) reinterpret_cast<int2*>(nodes)[idx] = make_int2(b, w * 32 + pos);
+  if (prev_idx || old_new) {
     int prev = -1;
-    if (((uint32_t)ow.x >> pos) & 1u) prev = ow.y + __popc((uint32_t)ow.x & ((1u << pos) - 1u));
+    if (bm_old) {
+      const int2 ow = bm_old[i];
+      if (((uint32_t)ow.x >> pos) & 1u) prev = ow.y + __popc((uint32_t)ow.x & ((1u << pos) - 1u));
+    }
     if (prev_idx) prev_idx[idx] = prev;
-    if (old_new && prev >= 0) old_new[prev] = idx;
-    ++idx;
+    if (old_new && prev >= 0) old_new[prev] = (int32_t)idx;
   }
 }
 
@@ -369,7 +371,8 @@ int rg_frontier_nodes(const rg_frontier* f, int32_t* nodes, int32_t* prev_idx, i
   const int2* bm_old = f->level > 0 ? f->bm_of(f->level - 1) : nullptr;
   RG_CHECK(!(old_new && !bm_old), "rg_frontier_nodes: level 0 has no previous level");
   const int64_t nw = (int64_t)f->B * f->W;
-  hipLaunchKernelGGL(emit_nodes_kernel, dim3(rg::ceil_div(nw, 256)), dim3(256), 0, s, f->bm_of(f->level), bm_old, f->B, f->W,
+  RG_CHECK(!nodes || ((uintptr_t)nodes & 7) == 0, "rg_frontier_nodes: nodes_out must be 8-byte aligned");
+  hipLaunchKernelGGL(emit_nodes_kernel, dim3(rg::ceil_div(nw * 32, 256)), dim3(256), 0, s, f->bm_of(f->level), bm_old, f->B, f->W,
                      nodes, prev_idx, old_new);
   RG_LAUNCH_CHECK();
   return 0;
