@@ -120,7 +120,7 @@ class BaseModel(object):
         ranks = []
         with torch.no_grad():
             for idx in _chunks(n_data, self.n_tbatch)[self.rank::self.world]:       # evaluation batches dealt round-robin
-                subs, rels, ans_ptr, ans_idx, filt_ptr, filt_idx = self.loader.get_batch_csr(idx, data=data)
+                subs, rels, ans_ptr, ans_idx, filt_ptr, filt_idx = self.loader.get_batch_csr(idx, data=data, device_queries=True)
                 scores = self.model(subs, rels, mode=mode)
                 ranks.append(cal_ranks_csr(scores, ans_ptr, ans_idx, filt_ptr, filt_idx))
         device = next(self.model.parameters()).device

@@ -130,7 +130,8 @@ class DataLoader:
             objs[i][answer[q]] = 1
         return subs, rels, objs
 
-    def get_batch_csr(self, batch_idx, data="valid"):
+    def get_batch_csr(self, batch_idx, data="valid", device_queries=False):
+        """As load_data.DataLoader.get_batch_csr (subs / rels stay numpy arrays here: the inductive splits are small)."""
         query, answer = (self.valid_q, self.valid_a) if data == "valid" else (self.test_q, self.test_a)
         filters = self.val_filters if data == "valid" else self.tst_filters
         subs = np.array([query[i][0] for i in batch_idx])

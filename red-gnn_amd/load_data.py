@@ -187,20 +187,24 @@ class DataLoader:
             ptr = lambda lists: np.concatenate([[0], np.cumsum([len(x) for x in lists])]).astype(np.int64)
             cat = lambda lists: np.concatenate(lists) if len(lists) else np.zeros(0, np.int64)
             to_dev = lambda a, dt: torch.as_tensor(np.asarray(a), dtype=dt).to(self.device)
-            cache[data] = (np.array([q[0] for q in query]), np.array([q[1] for q in query]), ptr(ans), to_dev(cat(ans), torch.int32),
-                           ptr(fil), to_dev(cat(fil), torch.int32))
+            subs, rels = np.array([q[0] for q in query]), np.array([q[1] for q in query])
+            cache[data] = (subs, rels, ptr(ans), to_dev(cat(ans), torch.int32), ptr(fil), to_dev(cat(fil), torch.int32),
+                           # device copies of the per-query arrays: a contiguous batch is then sliced without any host-to-device copy
+                           to_dev(subs, torch.int32), to_dev(rels, torch.int64), to_dev(ptr(ans), torch.int32), to_dev(ptr(fil), torch.int32))
         return cache[data]
 
-    def get_batch_csr(self, batch_idx, data="valid"):
+    def get_batch_csr(self, batch_idx, data="valid", device_queries=False):
         """The same batch as device CSR lists for the GPU ranker: (subs, rels, ans_ptr, ans_idx, filt_ptr, filt_idx).
-        batch_idx must be a contiguous range (as the evaluator's batches are) or any index array."""
-        subs_all, rels_all, aptr, aidx, fptr, fidx = self._split_csr(data)
+        batch_idx must be a contiguous range (as the evaluator's batches are) or any index array.  ``device_queries``: return
+        subs / rels of a contiguous batch as device tensors too (the evaluator's loop then issues no host-to-device copy)."""
+        subs_all, rels_all, aptr, aidx, fptr, fidx, subs_d, rels_d, aptr_d, fptr_d = self._split_csr(data)
         batch_idx = np.asarray(batch_idx)
         to_dev = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.int32).to(self.device)
         if len(batch_idx) and np.array_equal(batch_idx, np.arange(batch_idx[0], batch_idx[0] + len(batch_idx))):
             lo, hi = int(batch_idx[0]), int(batch_idx[-1]) + 1
-            return (subs_all[lo:hi], rels_all[lo:hi], to_dev(aptr[lo:hi + 1] - aptr[lo]), aidx[aptr[lo]:aptr[hi]],
-                    to_dev(fptr[lo:hi + 1] - fptr[lo]), fidx[fptr[lo]:fptr[hi]])
+            qs, qr = (subs_d[lo:hi], rels_d[lo:hi]) if device_queries else (subs_all[lo:hi], rels_all[lo:hi])
+            return (qs, qr, aptr_d[lo:hi + 1] - int(aptr[lo]), aidx[aptr[lo]:aptr[hi]],
+                    fptr_d[lo:hi + 1] - int(fptr[lo]), fidx[fptr[lo]:fptr[hi]])
         seg = lambda ptr, idx: torch.cat([idx[ptr[i]:ptr[i + 1]] for i in batch_idx]) if len(batch_idx) else idx[:0]
         lens = lambda ptr: np.concatenate([[0], np.cumsum([ptr[i + 1] - ptr[i] for i in batch_idx])])
         return subs_all[batch_idx], rels_all[batch_idx], to_dev(lens(aptr)), seg(aptr, aidx), to_dev(lens(fptr)), seg(fptr, fidx)

@@ -275,8 +275,11 @@ class RED_GNN_trans(nn.Module):
         engine._require_gpu(device)
         n = len(subs)
         graph = self.loader.graph_for(mode)
-        q_sub = torch.as_tensor(np.asarray(subs), dtype=torch.int32).to(device)
-        q_rel = torch.as_tensor(np.asarray(rels), dtype=torch.int64).to(device)
+        if torch.is_tensor(subs):        # device-resident batches (DataLoader.get_batch_csr) skip the host round trip
+            q_sub, q_rel = subs.to(device=device, dtype=torch.int32), torch.as_tensor(rels).to(device=device, dtype=torch.int64)
+        else:
+            q_sub = torch.as_tensor(np.asarray(subs), dtype=torch.int32).to(device)
+            q_rel = torch.as_tensor(np.asarray(rels), dtype=torch.int64).to(device)
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         n_ent = graph.n_ent                     # the inductive setting switches graphs (and n_ent) with the mode
         fused = not need_grad and self.fused_dense and engine.dense_supported(self.hidden_dim, self.attn_dim)
