@@ -328,7 +328,10 @@ struct DrelArgs {
   float* g_rela;
 };
 
-template <int G, int AP4>
+// TABLE: the relation gradient is accumulated in an LDS copy of the table (one LDS row add per segment, one global add per
+// block and row at the end).  When the table does not fit LDS (FB15k-237-like: 475 rows x 128) every segment's sum goes
+// straight to global memory: still one row add per <= 128 edges.
+template <int G, int AP4, bool TABLE>
 __global__ __launch_bounds__(BWD_BLOCK, 4) void drel_kernel(DrelArgs A) {
   extern __shared__ float4 lds[];
   constexpr int BLOCK = BWD_BLOCK;
@@ -337,7 +340,7 @@ __global__ __launch_bounds__(BWD_BLOCK, 4) void drel_kernel(DrelArgs A) {
   float4* stage = lds;                                   // [BLOCK] {o, alpha}
   float4* ar_l = stage + BLOCK;                          // [nr][AP4]
   float4* w_l = ar_l + nr * AP4;                         // [AP4]
-  float* grela_l = reinterpret_cast<float*>(w_l + AP4);  // [nr][RS]
+  float* grela_l = reinterpret_cast<float*>(w_l + AP4);  // [nr][RS]  (TABLE)
   for (int i = threadIdx.x; i < nr * AP4; i += BLOCK) ar_l[i] = A.a_r[i];
   if (threadIdx.x < AP4) {
     float w[4];
@@ -347,7 +350,7 @@ __global__ __launch_bounds__(BWD_BLOCK, 4) void drel_kernel(DrelArgs A) {
     }
     w_l[threadIdx.x] = make_float4(w[0], w[1], w[2], w[3]);
   }
-  for (int i = threadIdx.x; i < nr * RS; i += BLOCK) grela_l[i] = 0.f;
+  if constexpr (TABLE) { for (int i = threadIdx.x; i < nr * RS; i += BLOCK) grela_l[i] = 0.f; }
   __syncthreads();
   const float b_alpha = A.b_alpha[0];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -425,29 +428,44 @@ __global__ __launch_bounds__(BWD_BLOCK, 4) void drel_kernel(DrelArgs A) {
       }
     }
     if (live && any && row_lane) {
-      float* gr = grela_l + r * RS + lane_g;
-      atomicAdd(gr, acc.x); atomicAdd(gr + G, acc.y); atomicAdd(gr + 2 * G, acc.z); atomicAdd(gr + 3 * G, acc.w);
+      if constexpr (TABLE) {
+        float* gr = grela_l + r * RS + lane_g;
+        atomicAdd(gr, acc.x); atomicAdd(gr + G, acc.y); atomicAdd(gr + 2 * G, acc.z); atomicAdd(gr + 3 * G, acc.w);
+      } else {
+        float* gr = A.g_rela + ((int64_t)r * A.ld4 + lane_g) * 4;
+        atomicAdd(gr + 0, acc.x); atomicAdd(gr + 1, acc.y); atomicAdd(gr + 2, acc.z); atomicAdd(gr + 3, acc.w);
+      }
     }
   });
 
-  __syncthreads();
-  for (int i = threadIdx.x; i < nr * A.ld4 * 4; i += BLOCK) {
-    const int r = i / (A.ld4 * 4), c = i - r * (A.ld4 * 4);
-    const float v = grela_l[r * RS + (c & 3) * G + (c >> 2)];
-    if (v != 0.f) atomicAdd(A.g_rela + i, v);
+  if constexpr (TABLE) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < nr * A.ld4 * 4; i += BLOCK) {
+      const int r = i / (A.ld4 * 4), c = i - r * (A.ld4 * 4);
+      const float v = grela_l[r * RS + (c & 3) * G + (c >> 2)];
+      if (v != 0.f) atomicAdd(A.g_rela + i, v);
+    }
   }
 }
 
-template <int G, int AP4>
-int launch_drel(const DrelArgs& A, hipStream_t s) {
-  const size_t lds = (size_t)(BWD_BLOCK + A.n_rela_rows * AP4 + AP4) * sizeof(float4) + (size_t)A.n_rela_rows * (4 * G + 8) * sizeof(float);
-  auto kern = drel_kernel<G, AP4>;
+template <int G, int AP4, bool TABLE>
+int launch_drel_t(const DrelArgs& A, hipStream_t s) {
+  const size_t lds = (size_t)(BWD_BLOCK + A.n_rela_rows * AP4 + AP4) * sizeof(float4) +
+                     (TABLE ? (size_t)A.n_rela_rows * (4 * G + 8) * sizeof(float) : 0);
+  RG_CHECK(lds <= 160 * 1024, "rg_layer_bwd: attention table needs %zu B of LDS (> 160 KiB)", lds);
+  auto kern = drel_kernel<G, AP4, TABLE>;
   if (lds > 64 * 1024) RG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int grid = rg::walk_grid(A.walk.n_items, BWD_BLOCK, G, true, lds <= 80 * 1024 ? 2 : 1, 1);
   if (rg::zero_async(A.walk.queues, 8 * sizeof(int32_t), s)) return 1;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(BWD_BLOCK), lds, s, A);
   RG_LAUNCH_CHECK();
   return 0;
+}
+
+template <int G, int AP4>
+int launch_drel(const DrelArgs& A, hipStream_t s) {
+  const size_t table_lds = (size_t)(BWD_BLOCK + A.n_rela_rows * AP4 + AP4) * sizeof(float4) + (size_t)A.n_rela_rows * (4 * G + 8) * sizeof(float);
+  return table_lds <= 80 * 1024 ? launch_drel_t<G, AP4, true>(A, s) : launch_drel_t<G, AP4, false>(A, s);
 }
 
 template <int G>
@@ -591,10 +609,6 @@ extern "C" int rg_layer_bwd(const rg_frontier* f, const rg_graph* g, int32_t lev
   const bool dense = n_old >= 4 * (int64_t)f->B;
   const int ld4 = ld / 4;
   const int2* bm_old = f->bm_of(level - 1);
-  const int Gl = ld4 <= 4 ? 4 : ld4 <= 8 ? 8 : ld4 <= 16 ? 16 : ld4 <= 32 ? 32 : 64;
-  const size_t drel_lds = (size_t)(BWD_BLOCK + g->n_rela_rows * (ap / 4) + ap / 4) * sizeof(float4) +
-                          (size_t)g->n_rela_rows * (4 * Gl + 8) * sizeof(float);
-  if (drel_lds > 80 * 1024) A.diag |= 2;     // relation table too big for the relation-major pass: keep dRel in the main kernel
   int rc;
   if (ld4 <= 4) rc = launch_ap<4>(A, ap / 4, f->B, g->out_vr, bm_old, dense, s);
   else if (ld4 <= 8) rc = launch_ap<8>(A, ap / 4, f->B, g->out_vr, bm_old, dense, s);

@@ -822,3 +822,29 @@ def test_random_graphs_gradient_fuzz():
             tol = 2e-5 * max(1.0, float(np.abs(r).max()))
             bad = np.argwhere(~np.isclose(g, r, rtol=2e-3, atol=tol))
             np.testing.assert_allclose(g, r, rtol=2e-3, atol=tol, err_msg="case %d %s rows %s" % (case, k, np.unique(bad[:, 0]) if bad.size else []))
+
+
+@pytest.mark.parametrize("d", [64, 128])
+def test_backward_large_relation_table(d):
+    """FB15k-237-like relation count (481 rows x d does not fit the LDS copy the relation-major pass normally accumulates in):
+    the segments' sums go straight to global memory; forward and every gradient against autograd through the oracle."""
+    from red_gnn_amd.load_data import DataLoader
+    rng = np.random.default_rng(31)
+    n_ent, n_rel, m = 300, 240, 5000
+    facts = np.stack([rng.integers(0, n_ent, m), rng.integers(0, n_rel, m), rng.integers(0, n_ent, m)], 1)
+    facts[:700, 0] = 7                                        # a hub source
+    ids = _ids(n_ent, n_rel, facts[: (3 * m) // 4], train=facts[(3 * m) // 4:])
+    loader = DataLoader(ids=ids, verbose=False)
+    model = _random_model(loader, 2, d, 5, "tanh", seed=2).train()
+    B = 9
+    subs, rels = rng.integers(0, n_ent, B), rng.integers(0, 2 * n_rel, B)
+    weight = torch.tensor(rng.standard_normal((B, n_ent)), dtype=torch.float32)
+    s = model(subs, rels, mode="train")
+    (s * weight.cuda()).sum().backward()
+    p = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.named_parameters()}
+    ref = orc.forward(p, U.oracle_graph(ids, "train"), subs, rels, 2, act="tanh")
+    np.testing.assert_allclose(s.detach().cpu().numpy(), ref.detach().numpy(), rtol=RTOL, atol=ATOL_H)
+    (ref * weight).sum().backward()
+    for k, v in model.named_parameters():
+        r = p[k].grad.numpy()
+        np.testing.assert_allclose(v.grad.cpu().numpy(), r, rtol=2e-3, atol=2e-5 * max(1.0, float(np.abs(r).max())), err_msg=k)
