@@ -77,8 +77,9 @@ constexpr int BWD_BLOCK = 512;
 
 // DREL: accumulate dRel inside this kernel (run-length + LDS atomics).  When false the separate relation-major pass
 // (drel_kernel below) computes it and this kernel only needs rela rows for the attention gradient's dot product.
+// (AP4 >= 4, attn_dim > 12: 4 x AP4 float4 of per-edge attention state; 256 VGPRs instead of spilling at 128)
 template <int G, int AP4, bool PACKED, bool DENSE, bool RELA_LDS, bool DREL>
-__global__ __launch_bounds__(BWD_BLOCK, 4) void layer_bwd_kernel(BwdArgs A) {
+__global__ __launch_bounds__(BWD_BLOCK, AP4 >= 4 ? 2 : 4) void layer_bwd_kernel(BwdArgs A) {
   extern __shared__ float4 lds[];
   constexpr int BLOCK = BWD_BLOCK;
   const int nr = A.n_rela_rows;

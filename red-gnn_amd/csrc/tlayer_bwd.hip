@@ -66,8 +66,10 @@ __device__ __forceinline__ float group_sum(float v) {
 
 constexpr int TB_BLOCK = 512;
 
+// wide attention MLPs (AP4 >= 4: ICEWS presets use attn_dim = 30) keep 4 x AP4 float4 of per-edge state in registers: 256 VGPRs
+// (2 waves per SIMD; their LDS tables leave room for one workgroup per CU anyway) instead of spilling at 128
 template <int G, int AP4, bool DENSE>
-__global__ __launch_bounds__(TB_BLOCK, 4) void tlayer_bwd_kernel(TBwdArgs A) {
+__global__ __launch_bounds__(TB_BLOCK, AP4 >= 4 ? 2 : 4) void tlayer_bwd_kernel(TBwdArgs A) {
   extern __shared__ float4 lds[];
   constexpr int BLOCK = TB_BLOCK;
   const int nr = A.n_rela_rows;
