@@ -282,7 +282,9 @@ class RED_GNN_trans(nn.Module):
             q_rel = torch.as_tensor(np.asarray(rels), dtype=torch.int64).to(device)
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         n_ent = graph.n_ent                     # the inductive setting switches graphs (and n_ent) with the mode
-        fused = not need_grad and self.fused_dense and engine.dense_supported(self.hidden_dim, self.attn_dim)
+        # the fused kernels implement dropout as the identity: they serve eval mode (and training mode with p = 0) only
+        no_dropout = not self.training or self.dropout.p == 0.0
+        fused = not need_grad and no_dropout and self.fused_dense and engine.dense_supported(self.hidden_dim, self.attn_dim)
         if fused and self.use_graphs and trace is None and engine.KERNEL_EVENTS is None and engine.DENSE_EVENTS is None:
             out = self._forward_graphed(graph, q_sub, q_rel, n, device)
             if out is not None:
