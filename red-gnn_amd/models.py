@@ -248,7 +248,7 @@ class RED_GNN_trans(nn.Module):
         self._last_stats = None
         self.fused_dense = True      # inference: W_h + GRU + projections + readout in one MFMA kernel (rg_dense_fwd)
         self.use_graphs = True       # inference: replay a captured HIP graph per (graph, batch size) from the third call on
-        self._graphed, self._seen, self._hints, self._pending_key = {}, {}, {}, None
+        self._graphed, self._seen, self._hints, self._pending_key, self._graph_failed = {}, {}, {}, None, set()
 
     @property
     def last_stats(self):
@@ -336,9 +336,19 @@ class RED_GNN_trans(nn.Module):
                 self._pending_key = key          # the eager run that follows records its per-hop sizes under this key
                 return None
             hints = self._hints.get(key) or [n * graph.n_ent] * self.n_layer
+            if key in self._graph_failed:
+                return None
             if len(self._graphed) >= 3:
                 self._graphed.clear()
-            g = self._graphed[key] = _GraphedInference(self, graph, n, device, hints)
+            try:
+                g = self._graphed[key] = _GraphedInference(self, graph, n, device, hints)
+            except Exception as exc:      # capture refused (memory, a runtime that cannot capture here, ...): keep the eager HIP path
+                import warnings
+                warnings.warn("RED_GNN_trans: HIP graph capture failed for batch size %d (%s: %s); this shape stays on the eager "
+                              "path" % (n, type(exc).__name__, exc))
+                self._graph_failed.add(key)
+                torch.cuda.synchronize(device)
+                return None
         scores = g.run(q_sub, q_rel)
         self._last_stats = g.stats
         return scores
