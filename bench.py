@@ -125,6 +125,8 @@ def main():
     ap.add_argument("--family-eval", action="store_true", help="also time BaseModel.evaluate on the real family graph (n_tbatch=50, graph replay); "
                     "off by default so that a rocprofv3 run of the default command sees the C2 step's kernels only")
     ap.add_argument("--graphs", action="store_true", help="replay the forward as a captured HIP graph (no per-kernel HIP events, so no roofline object)")
+    ap.add_argument("--backend", default="nccl", help="process-group backend: nccl (= RCCL; one GPU per rank) or gloo (rehearsal of the "
+                    "N > 1 path with several ranks sharing one GPU)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group even at world size 1 (exercises the RCCL path on one GPU)")
     args = ap.parse_args()
 
@@ -133,6 +135,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
+    local_rank %= max(torch.cuda.device_count(), 1)          # (a gloo rehearsal may put several ranks on one GPU)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or args.force_dist:
@@ -141,7 +144,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
     from red_gnn_amd import engine
     from red_gnn_amd.load_data import DataLoader
@@ -259,7 +265,7 @@ def main():
             "config": {"workload": "%s synthetic KG %d entities / %d relations / %d triples (seed 1234), n_layer=%d hidden_dim=%d attn_dim=%d, "
                                    "eval step = expansion + fused layers + GRU/readout + filtered ranking, %d queries per GPU"
                                    % (args.config, kg.n_ent, kg.n_rel, shape["n_triples"], shape["n_layer"], d, shape["attn_dim"], B),
-                       "batch_per_gpu": B, "global_batch": B * world, "sharding": "queries over ranks, scores all-gathered (RCCL)" if world > 1 else "none"},
+                       "batch_per_gpu": B, "global_batch": B * world, "sharding": ("queries over ranks, scores all-gathered (%s)" % ("RCCL" if args.backend == "nccl" else args.backend)) if world > 1 else "none"},
             "eval_queries_per_s": B * world * args.steps / dt,
             "edges_per_step": total_edges / args.steps,
             "mrr_of_random_init": float(s[0] / s[3]),
