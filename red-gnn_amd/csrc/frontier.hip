@@ -13,13 +13,29 @@
 namespace {
 
 // ---- level 0: one node (b, q_sub[b]) per query ---------------------------------------------------
-__global__ void reset_kernel(const int32_t* __restrict__ q_sub, int B, int n_ent, int BW,
-                             uint32_t* __restrict__ bitsT, int32_t* counters) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
+// Level 0 of a query batch is one node per query, so its batch-major image needs no transpose / scan / pack passes:
+// bm[0][b][w] = {bit of q_sub[b] if it falls in word w, b + (w beyond that word)}; the same kernel sets the entity-major bits
+// (bitsT zeroed before) and the counters (N = B; the error flag for an id out of range).
+__global__ void reset_level0_kernel(const int32_t* __restrict__ q_sub, int B, int n_ent, int BW, int W, uint32_t* __restrict__ bitsT,
+                                    int2* __restrict__ bm0, int32_t* __restrict__ counters) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)B * W) return;
+  const int b = (int)(i / W), w = (int)(i - (int64_t)b * W);
   const int e = q_sub[b];
-  if (e < 0 || e >= n_ent) { atomicOr((unsigned*)&counters[1], 1u); return; }
-  atomicOr(&bitsT[(int64_t)e * BW + (b >> 5)], 1u << (b & 31));
+  const bool ok = e >= 0 && e < n_ent;
+  const int ew = ok ? e >> 5 : W;                    // an invalid start node contributes no bit (and raises the flag)
+  // nodes of earlier queries: b minus the invalid ones among them would be exact, but an invalid id is an error anyway
+  bm0[i] = make_int2(w == ew ? (int)(1u << (e & 31)) : 0, b + (w > ew ? 1 : 0));
+  if (w == 0) {
+    if (ok) atomicOr(&bitsT[(int64_t)e * BW + (b >> 5)], 1u << (b & 31));
+    else atomicOr((unsigned*)&counters[1], 1u);
+    if (b == 0) { counters[0] = B; counters[4] = B; }
+  }
+}
+
+// end of a hop: snapshot {N, error flag, E} of the new level for rg_frontier_level_counts
+__global__ void snapshot_kernel(int32_t* __restrict__ counters, int slot) {
+  if (threadIdx.x < 4) counters[slot + threadIdx.x] = counters[threadIdx.x];
 }
 
 __global__ void reset_nodes_kernel(const int32_t* __restrict__ nodes, int64_t n, int B, int n_ent, int BW,
@@ -265,11 +281,10 @@ int rg_frontier_reset(rg_frontier* f, const int32_t* q_sub, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   f->level = 0; f->tcur = 0; f->n_edges = 0;
   if (rg::zero_async(f->bitsT[0], (size_t)f->n_ent * f->BW * 4, s) || rg::zero_async(f->counters, 1024, s)) return 1;
-  hipLaunchKernelGGL(reset_kernel, dim3(rg::ceil_div(f->B, 256)), dim3(256), 0, s, q_sub, f->B, f->n_ent, f->BW,
-                     f->bitsT[0], f->counters);
+  const int64_t nw = (int64_t)f->B * f->W;
+  hipLaunchKernelGGL(reset_level0_kernel, dim3(rg::ceil_div(nw, 256)), dim3(256), 0, s, q_sub, f->B, f->n_ent, f->BW, f->W,
+                     f->bitsT[0], f->bm[0], f->counters);
   RG_LAUNCH_CHECK();
-  if (build_level(f, s)) return 1;
-  if (rg::copy_words_async(&f->counters[4], &f->counters[0], 1, s)) return 1;
   f->n_nodes[0] = f->B;   // one node per query; an out-of-range q_sub is reported by the next expand
   return 0;
 }
@@ -308,8 +323,10 @@ static int enqueue_expand(rg_frontier* f, const rg_graph* g, hipStream_t s) {
   f->tcur ^= 1;
   f->level += 1;
   if (build_level(f, s)) return 1;
-  if (f->level < RG_MAX_LEVELS)
-    if (rg::copy_words_async(&f->counters[64 + 8 * f->level], f->counters, 4, s)) return 1;
+  if (f->level < RG_MAX_LEVELS) {
+    hipLaunchKernelGGL(snapshot_kernel, dim3(1), dim3(64), 0, s, f->counters, 64 + 8 * f->level);
+    RG_LAUNCH_CHECK();
+  }
   return 0;
 }
 

@@ -278,8 +278,11 @@ class RED_GNN_trans(nn.Module):
         if torch.is_tensor(subs):        # device-resident batches (DataLoader.get_batch_csr) skip the host round trip
             q_sub, q_rel = subs.to(device=device, dtype=torch.int32), torch.as_tensor(rels).to(device=device, dtype=torch.int64)
         else:
-            q_sub = torch.as_tensor(np.asarray(subs), dtype=torch.int32).to(device)
-            q_rel = torch.as_tensor(np.asarray(rels), dtype=torch.int64).to(device)
+            subs_h, rels_h = np.asarray(subs), np.asarray(rels)
+            if n and (subs_h.min() < 0 or subs_h.max() >= graph.n_ent or rels_h.min() < 0 or rels_h.max() > 2 * self.n_rel):
+                raise ValueError("query subject / relation id out of range (n_ent=%d, 2*n_rel+1=%d)" % (graph.n_ent, 2 * self.n_rel + 1))
+            q_sub = torch.as_tensor(subs_h, dtype=torch.int32).to(device)
+            q_rel = torch.as_tensor(rels_h, dtype=torch.int64).to(device)
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         n_ent = graph.n_ent                     # the inductive setting switches graphs (and n_ent) with the mode
         # the fused kernels implement dropout as the identity: they serve eval mode (and training mode with p = 0) only

@@ -497,12 +497,17 @@ def test_edge_shapes_vs_oracle(n_ent, B):
 
 def test_bad_inputs_raise():
     from red_gnn_amd import _lib
+    from red_gnn_amd import engine as engine_mod
     from red_gnn_amd.load_data import DataLoader
     ids = _ids(10, 2, [[0, 0, 1], [1, 1, 2]])
     loader = DataLoader(ids=ids, verbose=False)
     model = _random_model(loader, 2, 16, 3, "relu")
+    with pytest.raises(ValueError):
+        model(np.array([0, 10]), np.array([0, 1]), mode="test")          # subject id == n_ent (checked on the host)
+    fr = engine_mod.Frontier(10, 2, 2, "cuda")
+    fr.reset(torch.tensor([0, 10], dtype=torch.int32, device="cuda"))
     with pytest.raises(_lib.NativeError):
-        model(np.array([0, 10]), np.array([0, 1]), mode="test")          # subject id == n_ent
+        fr.expand(loader.graph_for("test"))                              # ... and by the library when it gets that far
     with pytest.raises(_lib.NativeError):
         loader.get_neighbors(np.array([[0, 1], [0, 1]]), mode="test")    # duplicate start nodes
     with pytest.raises(_lib.NativeError):
