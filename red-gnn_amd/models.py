@@ -341,7 +341,11 @@ class RED_GNN_trans(nn.Module):
             hints = self._hints.get(key) or [n * graph.n_ent] * self.n_layer
             if key in self._graph_failed:
                 return None
-            if len(self._graphed) >= 3:
+            # a split's evaluation uses a few shapes (the batch size and the last, partial batches): keep them all, within a
+            # memory budget for the capacity-sized buffers
+            need = _GraphedInference.bytes_needed(n, graph.n_ent, ld, ap)
+            held = sum(_GraphedInference.bytes_needed(v.n, v.graph.n_ent, v.ld, v.ap) for v in self._graphed.values())
+            if len(self._graphed) >= 8 or held + need > 2 * _GraphedInference.MAX_BYTES:
                 self._graphed.clear()
             try:
                 g = self._graphed[key] = _GraphedInference(self, graph, n, device, hints)
