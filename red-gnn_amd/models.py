@@ -111,19 +111,13 @@ class GNNLayer(nn.Module):
         self.w_alpha = nn.Linear(attn_dim, 1)
         self.W_h = nn.Linear(in_dim, out_dim, bias=False)
 
-    def aggregate_nograd(self, q_rel, hidden_p, a_s, frontier, graph, level, nodes_new):
-        """Inference form of ``aggregate``: hidden_p [n_old, ld] already padded, a_s [n_old, ap] given
-        (produced by the previous layer's fused dense kernel).  Returns agg [n_new, ld]."""
-        d, a = self.in_dim, self.attn_dim
-        ld, ap = hidden_p.shape[1], a_s.shape[1]
-        rela = self.rela_embed.weight
-        pad_rows = lambda w: F.pad(w, (0, 0, 0, ap - a)) if ap != a else w
-        a_r = F.linear(rela, pad_rows(self.Wr_attn.weight))
-        a_q = F.linear(rela[q_rel], pad_rows(self.Wqr_attn.weight), F.pad(self.Wqr_attn.bias, (0, ap - a)))
-        if ld != d:
-            rela = F.pad(rela, (0, ld - d))
-        return engine.layer_fwd(frontier, graph, level, nodes_new, hidden_p, rela.contiguous(), d, a_s, a_r.contiguous(),
-                                a_q.contiguous(), self.w_alpha.weight.reshape(-1).contiguous(), self.w_alpha.bias, a)
+    def aggregate_nograd(self, tables, hidden_p, a_s, frontier, graph, level, nodes_new):
+        """Inference form of ``aggregate``: hidden_p [n_old, ld] already padded, a_s [n_old, ap] given (produced by the previous
+        layer's fused dense kernel), ``tables`` = this layer's (a_r, a_q, rela_p) from RED_GNN_trans.inference_tables.
+        Returns agg [n_new, ld]."""
+        a_r, a_q, rela_p = tables
+        return engine.layer_fwd(frontier, graph, level, nodes_new, hidden_p, rela_p, self.in_dim, a_s, a_r, a_q,
+                                self.w_alpha.weight.reshape(-1).contiguous(), self.w_alpha.bias, self.attn_dim)
 
     def aggregate(self, q_rel, hidden, frontier, graph, level, nodes_new, nodes_old):
         """models.py:29-39 on the device; returns message_agg [n_new, in_dim]."""
@@ -198,15 +192,12 @@ class _GraphedInference:
         hidden[:n].zero_()                                    # hidden == 0 at layer 0 (models.py:74)
         a_s[:n].zero_()
         self.scores.zero_()                                   # models.py:87
-        pad_rows = lambda w: F.pad(w, (0, 0, 0, ap - a)) if ap != a else w
+        tables = m.inference_tables(self.q_rel, ld, ap)
         for i in range(m.n_layer):
             layer = m.gnn_layers[i]
             fr.expand_async(graph)
             fr.nodes_into(self.nodes, self.prev)
-            rela = layer.rela_embed.weight
-            a_r = F.linear(rela, pad_rows(layer.Wr_attn.weight)).contiguous()
-            a_q = F.linear(rela[self.q_rel], pad_rows(layer.Wqr_attn.weight), F.pad(layer.Wqr_attn.bias, (0, ap - a))).contiguous()
-            rela_p = (F.pad(rela, (0, ld - d)) if ld != d else rela).contiguous()
+            a_r, a_q, rela_p = tables[i]
             engine.layer_fwd_into(fr, graph, fr.level, self.hints[i], hidden, rela_p, d, a_s, a_r, a_q,
                                   layer.w_alpha.weight.reshape(-1).contiguous(), layer.w_alpha.bias, a, self.agg, self.scratch)
             last = i + 1 == m.n_layer
@@ -322,6 +313,23 @@ class RED_GNN_trans(nn.Module):
         self.last_stats = dict(n_edges=n_edges, n_nodes=int(nodes_old.shape[0]))
         return scores_all.view(n, n_ent)
 
+    def inference_tables(self, q_rel, ld, ap):
+        """Per-layer attention tables of an inference forward for ALL layers in a dozen launches (they are tiny, so their launch
+        count - not their work - is what a small batch pays for): a_r[i] = Wr_i(rela_i) [2R+1, ap], a_q[i] = Wqr_i(rela_i[q_rel])
+        + b_i [B, ap] (models.py:33,36, the three attention Linear layers hoisted), rela_i padded to ld columns."""
+        d, a = self.hidden_dim, self.attn_dim
+        layers = self.gnn_layers
+        rela = torch.stack([l.rela_embed.weight for l in layers])                               # [L, 2R+1, d]
+        wr = torch.stack([l.Wr_attn.weight for l in layers])                                     # [L, a, d]
+        wq = torch.stack([l.Wqr_attn.weight for l in layers])
+        bq = torch.stack([l.Wqr_attn.bias for l in layers])                                      # [L, a]
+        if ap != a:
+            wr, wq, bq = F.pad(wr, (0, 0, 0, ap - a)), F.pad(wq, (0, 0, 0, ap - a)), F.pad(bq, (0, ap - a))
+        a_r = torch.bmm(rela, wr.transpose(1, 2))                                                # [L, 2R+1, ap]
+        a_q = torch.baddbmm(bq[:, None, :], rela[:, q_rel], wq.transpose(1, 2))                  # [L, B, ap]
+        rela_p = F.pad(rela, (0, ld - d)) if ld != d else rela
+        return [(a_r[i], a_q[i], rela_p[i]) for i in range(self.n_layer)]
+
     def _forward_graphed(self, graph, q_sub, q_rel, n, device):
         """Replay (or, on the third call with the same graph and batch size, capture) the forward as a HIP graph.
         Returns None when this call should run eagerly: the first two calls of a shape (the eager run also provides the
@@ -371,13 +379,14 @@ class RED_GNN_trans(nn.Module):
         scores_all = torch.zeros(n * n_ent, device=device)           # models.py:87
         n_edges, sizes = [], []
         nodes = None
+        tables = self.inference_tables(q_rel, ld, ap)
         for i in range(self.n_layer):
             n_new, n_e, _ = fr.expand(graph)
             nodes, prev_idx, old_new = fr.nodes(want_prev=True, want_old_new=trace is not None)
             n_edges.append(n_e)
             sizes.append(n_new)
             layer = self.gnn_layers[i]
-            agg = layer.aggregate_nograd(q_rel, hidden, a_s, fr, graph, fr.level, nodes)
+            agg = layer.aggregate_nograd(tables[i], hidden, a_s, fr, graph, fr.level, nodes)
             last = i + 1 == self.n_layer
             hidden, a_s = engine.dense_fwd(
                 agg, hidden, prev_idx, d, layer.W_h.weight, self.act_name, self.gate,
