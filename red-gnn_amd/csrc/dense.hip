@@ -32,7 +32,10 @@ __device__ __forceinline__ int sw(int row, int slot) { return row * (DP / 4) + (
 // (d = 128 streams them: dense128.hip).
 constexpr int DENSE_T = 512;
 
-template <int NB>
+// TRAIN: the same kernel also applies the dropout mask to the GRU input and writes what the backward pass needs - the GRU input
+// and the gate workspace in the layout of aten's fused GRU cell, so that its fused backward kernel can be reused - straight
+// from the accumulator layout (lane = node, 4 consecutive columns per register quad: 64-byte row segments).
+template <int NB, bool TRAIN>
 __global__ __launch_bounds__(DENSE_T, 2) void dense_kernel(DenseArgs A) {
   constexpr int DP = 16 * NB;      // padded width
   constexpr int S = DP / 4;        // 16-B slots per row
@@ -215,7 +218,7 @@ __global__ __launch_bounds__(DENSE_T, 2) void dense_kernel(DenseArgs A) {
         for (int ob = 0; ob < NB; ++ob) acc[ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ob].w, fx[4 * kb + 3], acc[ob], 0, 0, 0);
       }
 #pragma unroll
-      for (int ob = 0; ob < NB; ++ob)
+      for (int ob = 0; ob < NB; ++ob) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float v = acc[ob][r];
@@ -223,6 +226,19 @@ __global__ __launch_bounds__(DENSE_T, 2) void dense_kernel(DenseArgs A) {
           else if (A.act == 2) v = fast_tanh(v);
           xf[4 * ob + r] = v;
         }
+        if constexpr (TRAIN) {
+          const int64_t node = row0 + li;
+          const int col = 16 * ob + 4 * hq;
+          if (node < A.n && col < d) {
+            if (A.mask) {
+              const float4 mk = *reinterpret_cast<const float4*>(A.mask + node * (A.ld4 * 4) + col);
+              xf[4 * ob + 0] *= mk.x; xf[4 * ob + 1] *= mk.y; xf[4 * ob + 2] *= mk.z; xf[4 * ob + 3] *= mk.w;
+            }
+            *reinterpret_cast<float4*>(A.x_out + node * (A.ld4 * 4) + col) =
+                make_float4(xf[4 * ob + 0], xf[4 * ob + 1], xf[4 * ob + 2], xf[4 * ob + 3]);
+          }
+        }
+      }
     }
 
     // ---- GRU gates ([r; z; n] row blocks of weight_ih / weight_hh) -----------------------------------------
@@ -232,11 +248,25 @@ __global__ __launch_bounds__(DENSE_T, 2) void dense_kernel(DenseArgs A) {
       f32x4 ar = bias_acc(0, ob), az = bias_acc(1, ob), ai = bias_acc(2, ob), ah = bias_acc(3, ob);
       mma3(Wih_l, 0 * DP + 16 * ob, 1 * DP + 16 * ob, 2 * DP + 16 * ob, xf, ar, az, ai);
       if (any_old) mma3(Whh_l, 0 * DP + 16 * ob, 1 * DP + 16 * ob, 2 * DP + 16 * ob, hf, ar, az, ah);
+      float rgv[4], zgv[4], ngv[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float rg = fast_sigmoid(ar[r]), zg = fast_sigmoid(az[r]);
         const float ng = fast_tanh(ai[r] + rg * ah[r]);
         hn[4 * ob + r] = (1.0f - zg) * ng + zg * hf[4 * ob + r];
+        rgv[r] = rg; zgv[r] = zg; ngv[r] = ng;
+      }
+      if constexpr (TRAIN) {
+        const int64_t nd = row0 + li;
+        const int col = 16 * ob + 4 * hq;
+        if (nd < A.n && col < d) {
+          float* w = A.ws_out + nd * (5 * (int64_t)d) + col;
+          *reinterpret_cast<float4*>(w) = make_float4(rgv[0], rgv[1], rgv[2], rgv[3]);
+          *reinterpret_cast<float4*>(w + d) = make_float4(zgv[0], zgv[1], zgv[2], zgv[3]);
+          *reinterpret_cast<float4*>(w + 2 * d) = make_float4(ngv[0], ngv[1], ngv[2], ngv[3]);
+          *reinterpret_cast<float4*>(w + 3 * d) = make_float4(hf[4 * ob + 0], hf[4 * ob + 1], hf[4 * ob + 2], hf[4 * ob + 3]);
+          *reinterpret_cast<float4*>(w + 4 * d) = make_float4(ah[0], ah[1], ah[2], ah[3]);
+        }
       }
     }
 
@@ -271,13 +301,13 @@ __global__ __launch_bounds__(DENSE_T, 2) void dense_kernel(DenseArgs A) {
   }
 }
 
-template <int NB>
+template <int NB, bool TRAIN>
 int launch(const DenseArgs& A, hipStream_t s) {
   constexpr int DP = 16 * NB, S = DP / 4, NW = DENSE_T / 64;
   const size_t lds = (size_t)(7 * DP * S + 32 * S) * sizeof(float4) + 4 * DP * sizeof(float) + (size_t)NW * 16 * S * sizeof(float4);
-  RG_HIP(hipFuncSetAttribute((const void*)dense_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  RG_HIP(hipFuncSetAttribute((const void*)dense_kernel<NB, TRAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int grid = (int)std::min<int64_t>(rg::ceil_div(A.n_tiles, NW), 256);
-  hipLaunchKernelGGL((dense_kernel<NB>), dim3(grid), dim3(DENSE_T), lds, s, A);
+  hipLaunchKernelGGL((dense_kernel<NB, TRAIN>), dim3(grid), dim3(DENSE_T), lds, s, A);
   RG_LAUNCH_CHECK();
   return 0;
 }
@@ -312,7 +342,7 @@ static int dense_fwd_impl(int64_t n, const int32_t* n_dev, int32_t d, int32_t ld
   A.n_tiles = (int)rg::ceil_div(n, 16);
   hipStream_t s = (hipStream_t)stream;
   if (d == 128) return rg::dense128_launch(A, s);
-  return d <= 32 ? launch<2>(A, s) : launch<4>(A, s);
+  return d <= 32 ? launch<2, false>(A, s) : launch<4, false>(A, s);
 }
 
 extern "C" int rg_dense_fwd(int64_t n, int32_t d, int32_t ld, const float* agg, const float* hidden_prev,
@@ -332,4 +362,28 @@ extern "C" int rg_dense_fwd_dev(int64_t n_cap, const int32_t* n_dev, int32_t d, 
   RG_CHECK(n_dev != nullptr, "rg_dense_fwd_dev: n_dev is NULL");
   return dense_fwd_impl(n_cap, n_dev, d, ld, agg, hidden_prev, prev_idx, W_h, act, w_ih, w_hh, b_ih, b_hh, Ws_next, attn_dim, ap,
                         a_s_out, W_final, nodes, n_ent, scores_all, hidden_out, stream);
+}
+
+extern "C" int rg_dense_train_fwd(int64_t n, int32_t d, const float* agg, const float* hidden_prev, const int32_t* prev_idx,
+                                  const float* W_h, int32_t act, const float* w_ih, const float* w_hh, const float* b_ih,
+                                  const float* b_hh, const float* mask, float* hidden_out, float* x_out, float* gates_ws_out,
+                                  void* stream) {
+  RG_CHECK(agg && W_h && w_ih && w_hh && b_ih && b_hh && hidden_out && x_out && gates_ws_out, "rg_dense_train_fwd: NULL argument");
+  RG_CHECK(!prev_idx || hidden_prev, "rg_dense_train_fwd: prev_idx given without hidden_prev");
+  RG_CHECK(d >= 16 && d <= 64 && d % 4 == 0, "rg_dense_train_fwd: hidden_dim %d not supported (16..64, multiple of 4)", d);
+  RG_CHECK(act >= 0 && act <= 2, "rg_dense_train_fwd: act=%d", act);
+  RG_CHECK((((uintptr_t)agg | (uintptr_t)hidden_prev | (uintptr_t)hidden_out | (uintptr_t)x_out | (uintptr_t)gates_ws_out |
+             (uintptr_t)mask) & 15) == 0, "rg_dense_train_fwd: float buffers must be 16-B aligned");
+  if (n == 0) return 0;
+  DenseArgs A;
+  A.n = n; A.n_dev = nullptr; A.d = d; A.ld4 = d / 4;
+  A.agg = (const float4*)agg; A.hprev = (const float4*)hidden_prev; A.prev_idx = prev_idx;
+  A.W_h = W_h; A.w_ih = w_ih; A.w_hh = w_hh; A.b_ih = b_ih; A.b_hh = b_hh;
+  A.Ws = nullptr; A.attn = 0; A.ap = 0; A.a_s_out = nullptr;
+  A.W_final = nullptr; A.nodes = nullptr; A.n_ent = 0; A.scores = nullptr;
+  A.hidden_out = (float4*)hidden_out; A.act = act;
+  A.n_tiles = (int)rg::ceil_div(n, 16);
+  A.mask = mask; A.x_out = x_out; A.ws_out = gates_ws_out;
+  hipStream_t s = (hipStream_t)stream;
+  return d <= 32 ? launch<2, true>(A, s) : launch<4, true>(A, s);
 }

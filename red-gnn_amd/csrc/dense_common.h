@@ -29,6 +29,10 @@ struct DenseArgs {
   float4* hidden_out;      // [n][ld4]
   int act;                 // 0 idd, 1 relu, 2 tanh
   int n_tiles;
+  // training variant (rg_dense_train_fwd): dropout mask in, GRU input and gate workspace out
+  const float* mask = nullptr;   // [n][ld] 0 or 1/(1-p), or null
+  float* x_out = nullptr;        // [n][ld]  act(W_h agg) * mask
+  float* ws_out = nullptr;       // [n][5][d] = {r, z, n, h0, W_hn h0 + b_hn}: the workspace layout of aten's fused GRU cell
 };
 
 // v_exp_f32 / v_rcp_f32 forms (1 ulp each; __builtin_amdgcn_rcpf, not the correctly rounded __frcp_rn which expands

@@ -355,6 +355,25 @@ def dense_fwd_dev(n_cap, count_ptr, agg, hidden_prev, prev_idx, d, W_h, act, gat
                                            _lib.stream_ptr()))
 
 
+def dense_train_supported(d, act):
+    return 16 <= d <= 64 and d % 4 == 0 and act in ("idd", "relu", "tanh")
+
+
+def dense_train_fwd(agg, hidden_prev, prev_idx, W_h, act, gate, mask=None):
+    """rg_dense_train_fwd: (hidden_new [n,d], x [n,d], gates workspace [n,5d]) for the training step's dense part."""
+    n, d = agg.shape
+    dev = agg.device
+    hidden = torch.empty((n, d), dtype=torch.float32, device=dev)
+    x = torch.empty((n, d), dtype=torch.float32, device=dev)
+    ws = torch.empty((n, 5 * d), dtype=torch.float32, device=dev)
+    c = lambda t: None if t is None else t.detach().contiguous()
+    _lib.check(_lib.lib().rg_dense_train_fwd(n, d, _lib.ptr(c(agg)), _lib.ptr(c(hidden_prev)), _lib.ptr(prev_idx), _lib.ptr(c(W_h)),
+                                             {"idd": 0, "relu": 1, "tanh": 2}[act], _lib.ptr(c(gate.weight_ih_l0)),
+                                             _lib.ptr(c(gate.weight_hh_l0)), _lib.ptr(c(gate.bias_ih_l0)), _lib.ptr(c(gate.bias_hh_l0)),
+                                             _lib.ptr(c(mask)), _lib.ptr(hidden), _lib.ptr(x), _lib.ptr(ws), _lib.stream_ptr()))
+    return hidden, x, ws
+
+
 def rank(scores, ans_ptr, ans_idx, filt_ptr, filt_idx):
     """Filtered ranks (rg_rank) of every answer, fp32 [len(ans_idx)] in (query, answer) order."""
     assert scores.is_cuda and scores.dtype == torch.float32 and scores.is_contiguous()

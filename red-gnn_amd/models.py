@@ -33,15 +33,25 @@ _TALL_ROWS = 1 << 15        # below this a plain GEMM is as good
 _TALL_CHUNKS = 256          # ~ one row chunk per CU
 
 
+def _row_chunks(t, n_chunks, c):
+    """[n_chunks, c, cols] view of the first n_chunks * c rows of a 2-D tensor whose rows are unit-stride (rows may be spaced)."""
+    return t.as_strided((n_chunks, c, t.shape[1]), (c * t.stride(0), t.stride(0), 1), t.storage_offset())
+
+
 def _gram_tn(g, x):
     """g^T x for g [N,m], x [N,n] with N >> m,n: chunks of rows as one batched GEMM, then a sum over the chunks
-    (fills the chip and shortens every fp32 accumulation chain by the chunk count)."""
+    (fills the chip and shortens every fp32 accumulation chain by the chunk count).  Rows need unit-stride columns only
+    (a column block of a wider matrix works without a copy)."""
+    if g.stride(1) != 1:
+        g = g.contiguous()
+    if x.stride(1) != 1:
+        x = x.contiguous()
     n_rows = g.shape[0]
     if n_rows < _TALL_ROWS:
         return g.t() @ x
     c = n_rows // _TALL_CHUNKS
     body = _TALL_CHUNKS * c
-    out = torch.bmm(g[:body].view(_TALL_CHUNKS, c, -1).transpose(1, 2), x[:body].view(_TALL_CHUNKS, c, -1)).sum(0)
+    out = torch.bmm(_row_chunks(g, _TALL_CHUNKS, c).transpose(1, 2), _row_chunks(x, _TALL_CHUNKS, c)).sum(0)
     if body < n_rows:
         out = out + g[body:].t() @ x[body:]
     return out
@@ -61,7 +71,7 @@ class _TallLinear(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         g = g.contiguous()
         gx = g @ weight if ctx.needs_input_grad[0] else None
-        gw = _gram_tn(g, x.contiguous()) if ctx.needs_input_grad[1] else None
+        gw = _gram_tn(g, x) if ctx.needs_input_grad[1] else None
         gb = g.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return gx, gw, gb
 
@@ -96,6 +106,46 @@ class _Aggregate(torch.autograd.Function):
         g_h, g_rela, g_as, g_ar, g_aq, g_w, g_b = engine.layer_bwd(
             frontier, graph, level, nodes_old, hidden, rela, d, a_s, a_r, a_q, w_alpha, b_alpha, attn_dim, grad_agg)
         return g_h, g_rela, g_as, g_ar, g_aq, g_w.view_as(w_alpha), g_b.view_as(b_alpha), None, None, None, None, None, None, None
+
+
+class _DenseStep(torch.autograd.Function):
+    """hidden_new = GRU(dropout(act(agg W_h^T)), h0 carried from the previous frontier)  -  models.py:41,81-83 of one layer.
+
+    Forward: one fused f32-MFMA kernel (rg_dense_train_fwd) that also leaves the GRU input and the gate workspace in the layout of
+    PyTorch's fused GRU cell.  Backward: that cell's own fused backward kernel for the gates, row-chunked batched GEMMs for the
+    five weight gradients (_gram_tn), plain GEMMs for the input gradients; the carry's gradient is a gather (every old node is
+    exactly one new node)."""
+
+    @staticmethod
+    def forward(ctx, agg, hidden_prev, W_h, w_ih, w_hh, b_ih, b_hh, prev_idx, old_new, mask, act, gate, keep):
+        agg, hidden_prev = agg.contiguous(), hidden_prev.contiguous()
+        hidden, x, ws = engine.dense_train_fwd(agg, hidden_prev, prev_idx, W_h, act, gate, mask)
+        ctx.save_for_backward(agg, x, ws, W_h, w_ih, w_hh, old_new, mask if mask is not None else agg.new_zeros(0))
+        ctx.act, ctx.keep, ctx.n_old = act, keep, hidden_prev.shape[0]
+        return hidden
+
+    @staticmethod
+    def backward(ctx, g_h):
+        agg, x, ws, W_h, w_ih, w_hh, old_new, mask = ctx.saved_tensors
+        n, d = agg.shape
+        dgi, dgh, dh0, dbi, dbh = torch.ops.aten._thnn_fused_gru_cell_backward(g_h.contiguous(), ws, True)
+        h0 = ws.view(n, 5, d)[:, 3]                          # a column block of the workspace: no copy
+        dx = dgi @ w_ih
+        dh0 = dh0 + dgh @ w_hh
+        g_wih, g_whh = _gram_tn(dgi, x), _gram_tn(dgh, h0)
+        if mask.numel():
+            dx = dx * mask
+        if ctx.act == "relu":
+            dpre = dx * (x > 0)
+        elif ctx.act == "tanh":
+            y = x * ctx.keep if mask.numel() else x            # x = tanh(pre) / keep where kept; dx is 0 where dropped
+            dpre = dx * (1.0 - y * y)
+        else:
+            dpre = dx
+        g_agg = dpre @ W_h
+        g_wh = _gram_tn(dpre, agg)
+        g_prev = dh0[old_new.long()] if ctx.n_old else dh0.new_zeros((0, d))
+        return g_agg, g_prev, g_wh, g_wih, g_whh, dbi, dbh, None, None, None, None, None, None
 
 
 class GNNLayer(nn.Module):
@@ -294,15 +344,27 @@ class RED_GNN_trans(nn.Module):
         nodes_old = torch.stack([torch.arange(n, device=device, dtype=torch.int32), q_sub], 1)   # models.py:73
         g = self.gate
         n_edges = []
+        fused_train = self.fused_dense and engine.dense_train_supported(d, self.act_name)
         for i in range(self.n_layer):                                            # models.py:77
             n_new, n_e, _ = fr.expand(graph)                                     # models.py:78 (on the device)
-            nodes, _, old_new = fr.nodes(want_prev=False)
+            nodes, prev_idx, old_new = fr.nodes(want_prev=fused_train)
             n_edges.append(n_e)
             engine.prefer_blas(n_new)
-            hidden = self.gnn_layers[i](q_sub, q_rel, hidden, fr, graph, fr.level, nodes, nodes_old)   # models.py:80
-            h0 = torch.zeros((n_new, d), device=device).index_copy(0, old_new.long(), h0)           # models.py:81
-            hidden = self.dropout(hidden)                                        # models.py:82
-            hidden = gru_step(hidden, h0, g)                                     # models.py:83
+            layer = self.gnn_layers[i]
+            if fused_train:
+                # models.py:80-83 with the dense part in one kernel: W_h + act, h0 carry (gather by prev_idx), dropout, GRU step
+                agg = layer.aggregate(q_rel, hidden, fr, graph, fr.level, nodes, nodes_old)
+                mask = None
+                if self.training and self.dropout.p > 0.0:
+                    keep = 1.0 - self.dropout.p
+                    mask = torch.empty((n_new, d), device=device).bernoulli_(keep).div_(keep)
+                hidden = _DenseStep.apply(agg, h0, layer.W_h.weight, g.weight_ih_l0, g.weight_hh_l0, g.bias_ih_l0, g.bias_hh_l0,
+                                          prev_idx, old_new, mask, self.act_name, g, 1.0 - self.dropout.p)
+            else:
+                hidden = layer(q_sub, q_rel, hidden, fr, graph, fr.level, nodes, nodes_old)                # models.py:80
+                h0 = torch.zeros((n_new, d), device=device).index_copy(0, old_new.long(), h0)           # models.py:81
+                hidden = self.dropout(hidden)                                        # models.py:82
+                hidden = gru_step(hidden, h0, g)                                     # models.py:83
             h0 = hidden
             if trace is not None:
                 trace.append(dict(nodes=nodes, old_nodes_new_idx=old_new, n_edges=n_e, hidden=hidden))

@@ -853,3 +853,38 @@ def test_backward_large_relation_table(d):
     for k, v in model.named_parameters():
         r = p[k].grad.numpy()
         np.testing.assert_allclose(v.grad.cpu().numpy(), r, rtol=2e-3, atol=2e-5 * max(1.0, float(np.abs(r).max())), err_msg=k)
+
+
+@pytest.mark.parametrize("act", ["relu", "tanh", "idd"])
+@pytest.mark.parametrize("d,n", [(16, 37), (48, 1000), (64, 4099)])
+def test_fused_training_dense_step_with_dropout_mask(act, d, n):
+    """models._DenseStep (rg_dense_train_fwd + the manual backward) with a dropout mask, against the same step in torch ops
+    (W_h, act, mask, index_copy carry, gru_cell) and autograd: output and the gradients of all seven inputs."""
+    from red_gnn_amd.models import _DenseStep
+    torch.manual_seed(n + d)
+    dev = "cuda"
+    n_old = max(1, n // 3)
+    acts = {"relu": torch.relu, "tanh": torch.tanh, "idd": lambda v: v}
+    gate = torch.nn.GRU(d, d).to(dev)
+    leaf = lambda *shape: torch.randn(*shape, device=dev).requires_grad_(True)
+    agg, hprev, W_h = leaf(n, d), leaf(n_old, d), (torch.randn(d, d, device=dev) / d ** 0.5).requires_grad_(True)
+    sel = torch.randperm(n, device=dev)[:n_old]
+    prev = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    prev[sel] = torch.arange(n_old, dtype=torch.int32, device=dev)
+    old_new = sel.int()
+    keep = 0.7
+    mask = torch.empty(n, d, device=dev).bernoulli_(keep).div_(keep)
+    w = torch.randn(n, d, device=dev)
+    params = [agg, hprev, W_h, gate.weight_ih_l0, gate.weight_hh_l0, gate.bias_ih_l0, gate.bias_hh_l0]
+
+    out = _DenseStep.apply(agg, hprev, W_h, gate.weight_ih_l0, gate.weight_hh_l0, gate.bias_ih_l0, gate.bias_hh_l0, prev, old_new,
+                           mask, act, gate, keep)
+    g1 = torch.autograd.grad((out * w).sum(), params)
+    x = acts[act](agg @ W_h.t()) * mask
+    h0 = torch.zeros(n, d, device=dev).index_copy(0, old_new.long(), hprev)
+    ref = torch.gru_cell(x, h0, gate.weight_ih_l0, gate.weight_hh_l0, gate.bias_ih_l0, gate.bias_hh_l0)
+    g2 = torch.autograd.grad((ref * w).sum(), params)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().cpu().numpy(), rtol=RTOL, atol=ATOL_H)
+    for a_, b_, name in zip(g1, g2, ["agg", "hidden_prev", "W_h", "w_ih", "w_hh", "b_ih", "b_hh"]):
+        r = b_.cpu().numpy()
+        np.testing.assert_allclose(a_.cpu().numpy(), r, rtol=2e-3, atol=2e-5 * max(1.0, float(np.abs(r).max())), err_msg=name)
