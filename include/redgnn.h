@@ -204,7 +204,7 @@ int rg_dense_fwd_dev(int64_t n_cap, const int32_t* n_dev, int32_t d, int32_t ld,
 /* ---- dense step of a layer in training: models.py:41 (W_h + act), :81 (h0 carry), :82 (dropout, as a given mask: 0 or
  * 1/(1-p) per element, or NULL), :83 (single-step GRU) in one f32-MFMA kernel that also leaves what the backward pass needs:
  * x_out [n,d] = the GRU input, and gates_ws_out [n,5,d] = {r, z, n, h0, W_hn h0 + b_hn}, the workspace layout of PyTorch's fused
- * GRU cell (so its fused backward kernel applies).  d in 16..64, multiple of 4; rows are d floats wide (no padding). */
+ * GRU cell (so its fused backward kernel applies).  d in 16..64 (multiple of 4) or 128; rows are d floats wide (no padding). */
 int rg_dense_train_fwd(int64_t n, int32_t d, const float* agg, const float* hidden_prev, const int32_t* prev_idx,
                        const float* W_h, int32_t act, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
                        const float* mask, float* hidden_out, float* x_out, float* gates_ws_out, void* stream);

@@ -370,7 +370,7 @@ extern "C" int rg_dense_train_fwd(int64_t n, int32_t d, const float* agg, const 
                                   void* stream) {
   RG_CHECK(agg && W_h && w_ih && w_hh && b_ih && b_hh && hidden_out && x_out && gates_ws_out, "rg_dense_train_fwd: NULL argument");
   RG_CHECK(!prev_idx || hidden_prev, "rg_dense_train_fwd: prev_idx given without hidden_prev");
-  RG_CHECK(d >= 16 && d <= 64 && d % 4 == 0, "rg_dense_train_fwd: hidden_dim %d not supported (16..64, multiple of 4)", d);
+  RG_CHECK((d >= 16 && d <= 64 && d % 4 == 0) || d == 128, "rg_dense_train_fwd: hidden_dim %d not supported (16..64 in steps of 4, or 128)", d);
   RG_CHECK(act >= 0 && act <= 2, "rg_dense_train_fwd: act=%d", act);
   RG_CHECK((((uintptr_t)agg | (uintptr_t)hidden_prev | (uintptr_t)hidden_out | (uintptr_t)x_out | (uintptr_t)gates_ws_out |
              (uintptr_t)mask) & 15) == 0, "rg_dense_train_fwd: float buffers must be 16-B aligned");
@@ -385,5 +385,6 @@ extern "C" int rg_dense_train_fwd(int64_t n, int32_t d, const float* agg, const 
   A.n_tiles = (int)rg::ceil_div(n, 16);
   A.mask = mask; A.x_out = x_out; A.ws_out = gates_ws_out;
   hipStream_t s = (hipStream_t)stream;
+  if (d == 128) return rg::dense128_launch(A, s);
   return d <= 32 ? launch<2, true>(A, s) : launch<4, true>(A, s);
 }

@@ -25,6 +25,8 @@ constexpr int NL = 16 * S / 64;   // float4 per lane of a 16-row tile
 
 __device__ __forceinline__ int swz(int row, int slot) { return row * S + (slot ^ (row & (S - 1))); }
 
+// TRAIN: as in dense.hip (dropout mask in; GRU input and gate workspace out, straight from the accumulator layout)
+template <bool TRAIN>
 __global__ __launch_bounds__(T, 2) void dense128_kernel(DenseArgs A) {
   extern __shared__ float4 lds[];
   if (A.n_dev) { A.n = *A.n_dev; A.n_tiles = (int)((A.n + 15) / 16); }      // the grid was sized for the capacity
@@ -195,6 +197,17 @@ __global__ __launch_bounds__(T, 2) void dense128_kernel(DenseArgs A) {
         else if (A.act == 2) v = fast_tanh(v);
         xf[4 * ob + r] = v;
       }
+      if constexpr (TRAIN) {
+        const int64_t nd = row0 + li;
+        const int col = 16 * ob + 4 * hq;
+        if (nd < A.n) {
+          if (A.mask) {
+            const float4 mk = *reinterpret_cast<const float4*>(A.mask + nd * DP + col);
+            xf[4 * ob + 0] *= mk.x; xf[4 * ob + 1] *= mk.y; xf[4 * ob + 2] *= mk.z; xf[4 * ob + 3] *= mk.w;
+          }
+          *reinterpret_cast<float4*>(A.x_out + nd * DP + col) = make_float4(xf[4 * ob + 0], xf[4 * ob + 1], xf[4 * ob + 2], xf[4 * ob + 3]);
+        }
+      }
     };
     {
       f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0;
@@ -239,6 +252,18 @@ __global__ __launch_bounds__(T, 2) void dense128_kernel(DenseArgs A) {
         const float rg = fast_sigmoid(ar[r]), zg = fast_sigmoid(az[r]);
         const float ng = fast_tanh(ai[r] + rg * ah[r]);
         hn[4 * ob + r] = (1.0f - zg) * ng + zg * hf[4 * ob + r];
+        if constexpr (TRAIN) { ar[r] = rg; az[r] = zg; ai[r] = ng; }
+      }
+      if constexpr (TRAIN) {
+        const int64_t nd = row0 + li;
+        if (nd < A.n) {
+          float* w = A.ws_out + nd * (5 * (int64_t)DP) + 16 * ob + 4 * hq;
+          *reinterpret_cast<float4*>(w) = make_float4(ar[0], ar[1], ar[2], ar[3]);
+          *reinterpret_cast<float4*>(w + DP) = make_float4(az[0], az[1], az[2], az[3]);
+          *reinterpret_cast<float4*>(w + 2 * DP) = make_float4(ai[0], ai[1], ai[2], ai[3]);
+          *reinterpret_cast<float4*>(w + 3 * DP) = make_float4(hf[4 * ob + 0], hf[4 * ob + 1], hf[4 * ob + 2], hf[4 * ob + 3]);
+          *reinterpret_cast<float4*>(w + 4 * DP) = make_float4(ah[0], ah[1], ah[2], ah[3]);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -277,9 +302,10 @@ __global__ __launch_bounds__(T, 2) void dense128_kernel(DenseArgs A) {
 int dense128_launch(const DenseArgs& A, hipStream_t s) {
   RG_CHECK(A.d == DP && A.ld4 == S, "rg_dense_fwd: the d = 128 kernel needs ld = 128 (got d=%d ld=%d)", A.d, A.ld4 * 4);
   const size_t lds = (size_t)(2 * CHUNK + 32 * S + NW * 16 * S) * sizeof(float4) + 4 * DP * sizeof(float);
-  RG_HIP(hipFuncSetAttribute((const void*)dense128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  auto kern = A.ws_out ? dense128_kernel<true> : dense128_kernel<false>;
+  RG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int grid = (int)std::min<int64_t>(ceil_div(A.n_tiles, NW), 256);
-  hipLaunchKernelGGL(dense128_kernel, dim3(grid), dim3(T), lds, s, A);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(T), lds, s, A);
   RG_LAUNCH_CHECK();
   return 0;
 }

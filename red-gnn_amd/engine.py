@@ -356,7 +356,7 @@ def dense_fwd_dev(n_cap, count_ptr, agg, hidden_prev, prev_idx, d, W_h, act, gat
 
 
 def dense_train_supported(d, act):
-    return 16 <= d <= 64 and d % 4 == 0 and act in ("idd", "relu", "tanh")
+    return ((16 <= d <= 64 and d % 4 == 0) or d == 128) and act in ("idd", "relu", "tanh")
 
 
 def dense_train_fwd(agg, hidden_prev, prev_idx, W_h, act, gate, mask=None):
