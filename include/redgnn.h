@@ -209,6 +209,14 @@ int rg_dense_train_fwd(int64_t n, int32_t d, const float* agg, const float* hidd
                        const float* W_h, int32_t act, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
                        const float* mask, float* hidden_out, float* x_out, float* gates_ws_out, void* stream);
 
+/* Adjoint of rg_dense_train_fwd for the node-row quantities (autograd of models.py:41,81-83): from grad_hidden [n,d] and the saved
+ * x / gates_ws (/ mask, keep = 1 - p) it writes grad_gates_i, grad_gates_h [n,3d] (GRU pre-activation gradients, for the weight and
+ * bias gradients the caller forms), grad_pre [n,d] (gradient at W_h's output, for dW_h), grad_agg [n,d] and grad_h0 [n,d] (the
+ * carried state's gradient, to be gathered back to the previous frontier by old_nodes_new_idx).  d in 16..64, multiple of 4. */
+int rg_dense_train_bwd(int64_t n, int32_t d, const float* grad_hidden, const float* gates_ws, const float* x, const float* mask,
+                       float keep, int32_t act, const float* W_h, const float* w_ih, const float* w_hh,
+                       float* grad_gates_i, float* grad_gates_h, float* grad_pre, float* grad_agg, float* grad_h0, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

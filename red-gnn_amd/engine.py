@@ -374,6 +374,23 @@ def dense_train_fwd(agg, hidden_prev, prev_idx, W_h, act, gate, mask=None):
     return hidden, x, ws
 
 
+def dense_train_bwd_supported(d):
+    return 16 <= d <= 64 and d % 4 == 0
+
+
+def dense_train_bwd(g_h, ws, x, mask, keep, act, W_h, w_ih, w_hh):
+    """rg_dense_train_bwd: (dgi [n,3d], dgh [n,3d], dpre [n,d], dagg [n,d], dh0 [n,d])."""
+    n, d = x.shape
+    dev = x.device
+    f = lambda cols: torch.empty((n, cols), dtype=torch.float32, device=dev)
+    dgi, dgh, dpre, dagg, dh0 = f(3 * d), f(3 * d), f(d), f(d), f(d)
+    c = lambda t: None if t is None else t.detach().contiguous()
+    _lib.check(_lib.lib().rg_dense_train_bwd(n, d, _lib.ptr(c(g_h)), _lib.ptr(ws), _lib.ptr(x), _lib.ptr(c(mask)), float(keep),
+                                             {"idd": 0, "relu": 1, "tanh": 2}[act], _lib.ptr(c(W_h)), _lib.ptr(c(w_ih)), _lib.ptr(c(w_hh)),
+                                             _lib.ptr(dgi), _lib.ptr(dgh), _lib.ptr(dpre), _lib.ptr(dagg), _lib.ptr(dh0), _lib.stream_ptr()))
+    return dgi, dgh, dpre, dagg, dh0
+
+
 def rank(scores, ans_ptr, ans_idx, filt_ptr, filt_idx):
     """Filtered ranks (rg_rank) of every answer, fp32 [len(ans_idx)] in (query, answer) order."""
     assert scores.is_cuda and scores.dtype == torch.float32 and scores.is_contiguous()

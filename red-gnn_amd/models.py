@@ -29,6 +29,8 @@ def _pad4(n):
     return (n + 3) // 4 * 4
 
 
+_FUSED_BWD_ROWS = 1 << 13   # below this the fused dense adjoint's prologue (three transposed weight images per workgroup) costs
+                            # more than aten's GRU-cell backward and three small GEMMs
 _TALL_ROWS = 1 << 15        # below this a plain GEMM is as good
 _TALL_CHUNKS = 256          # ~ one row chunk per CU
 
@@ -128,21 +130,28 @@ class _DenseStep(torch.autograd.Function):
     def backward(ctx, g_h):
         agg, x, ws, W_h, w_ih, w_hh, old_new, mask = ctx.saved_tensors
         n, d = agg.shape
-        dgi, dgh, dh0, dbi, dbh = torch.ops.aten._thnn_fused_gru_cell_backward(g_h.contiguous(), ws, True)
-        h0 = ws.view(n, 5, d)[:, 3]                          # a column block of the workspace: no copy
-        dx = dgi @ w_ih
-        dh0 = dh0 + dgh @ w_hh
-        g_wih, g_whh = _gram_tn(dgi, x), _gram_tn(dgh, h0)
-        if mask.numel():
-            dx = dx * mask
-        if ctx.act == "relu":
-            dpre = dx * (x > 0)
-        elif ctx.act == "tanh":
-            y = x * ctx.keep if mask.numel() else x            # x = tanh(pre) / keep where kept; dx is 0 where dropped
-            dpre = dx * (1.0 - y * y)
+        has_mask = mask.numel() > 0
+        if engine.dense_train_bwd_supported(d) and n >= _FUSED_BWD_ROWS:
+            # one fused kernel for everything per node row (rg_dense_train_bwd); the weight gradients below are sums over rows
+            dgi, dgh, dpre, g_agg, dh0 = engine.dense_train_bwd(g_h, ws, x, mask if has_mask else None, ctx.keep, ctx.act, W_h, w_ih, w_hh)
+            dbi, dbh = dgi.sum(0), dgh.sum(0)
+            h0 = ws.view(n, 5, d)[:, 3]                          # a column block of the workspace: no copy
         else:
-            dpre = dx
-        g_agg = dpre @ W_h
+            dgi, dgh, dh0, dbi, dbh = torch.ops.aten._thnn_fused_gru_cell_backward(g_h.contiguous(), ws, True)
+            h0 = ws.view(n, 5, d)[:, 3]
+            dx = dgi @ w_ih
+            dh0 = dh0 + dgh @ w_hh
+            if has_mask:
+                dx = dx * mask
+            if ctx.act == "relu":
+                dpre = dx * (x > 0)
+            elif ctx.act == "tanh":
+                y = x * ctx.keep if has_mask else x              # x = tanh(pre) / keep where kept; dx is 0 where dropped
+                dpre = dx * (1.0 - y * y)
+            else:
+                dpre = dx
+            g_agg = dpre @ W_h
+        g_wih, g_whh = _gram_tn(dgi, x), _gram_tn(dgh, h0)
         g_wh = _gram_tn(dpre, agg)
         g_prev = dh0[old_new.long()] if ctx.n_old else dh0.new_zeros((0, d))
         return g_agg, g_prev, g_wh, g_wih, g_whh, dbi, dbh, None, None, None, None, None, None

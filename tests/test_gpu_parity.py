@@ -856,7 +856,7 @@ def test_backward_large_relation_table(d):
 
 
 @pytest.mark.parametrize("act", ["relu", "tanh", "idd"])
-@pytest.mark.parametrize("d,n", [(16, 37), (48, 1000), (64, 4099), (128, 300), (128, 2049)])
+@pytest.mark.parametrize("d,n", [(16, 37), (48, 1000), (64, 4099), (128, 300), (128, 2049), (16, 9000), (48, 20000), (64, 33000)])
 def test_fused_training_dense_step_with_dropout_mask(act, d, n):
     """models._DenseStep (rg_dense_train_fwd + the manual backward) with a dropout mask, against the same step in torch ops
     (W_h, act, mask, index_copy carry, gru_cell) and autograd: output and the gradients of all seven inputs."""
