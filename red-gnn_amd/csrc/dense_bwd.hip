@@ -137,6 +137,7 @@ __global__ __launch_bounds__(DB_T, 2) void dense_bwd_kernel(DenseBwdArgs A) {
         acc_dx[o] = mfma4(a2, dn, acc_dx[o]);
         acc_dh[o] = mfma4(b2, dnr, acc_dh[o]);
       }
+      __builtin_amdgcn_sched_barrier(0);      // one block's loads in flight at a time: all four at once do not fit 256 registers
     }
 
     // ---- d h0, dpre (dropout mask, activation derivative) --------------------------------------------------------------
