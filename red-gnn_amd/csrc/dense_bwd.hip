@@ -91,16 +91,27 @@ __global__ __launch_bounds__(DB_T, 2) void dense_bwd_kernel(DenseBwdArgs A) {
 #pragma unroll
     for (int o = 0; o < NB; ++o) { acc_dx[o] = zero4; acc_dh[o] = zero4; }
     float gz[KS];                                   // g * z, the direct part of d h0
+    // the six row segments of block ob + 1 are requested before block ob's MFMAs are issued (explicit double buffer: left to
+    // itself the compiler requests all four blocks at once and spills, fenced off it requests each block just in time)
+    auto fetch = [&](int ob, float4 (&v)[6]) {
+      const int col = 16 * ob + 4 * hq;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (in_n && col < d) {
+        v[0] = ld4(A.g_h, node, d, col);
+        v[1] = ld4(A.ws, node, 5 * d, col); v[2] = ld4(A.ws, node, 5 * d, d + col); v[3] = ld4(A.ws, node, 5 * d, 2 * d + col);
+        v[4] = ld4(A.ws, node, 5 * d, 3 * d + col); v[5] = ld4(A.ws, node, 5 * d, 4 * d + col);
+      }
+    };
+    float4 cur[6], nxt[6];
+    fetch(0, cur);
 #pragma unroll
     for (int ob = 0; ob < NB; ++ob) {
       const int col = 16 * ob + 4 * hq;
       const bool ok = in_n && col < d;
-      float4 g = make_float4(0.f, 0.f, 0.f, 0.f), r = g, z = g, nn = g, h0 = g, hp = g;
-      if (ok) {
-        g = ld4(A.g_h, node, d, col);
-        r = ld4(A.ws, node, 5 * d, col); z = ld4(A.ws, node, 5 * d, d + col); nn = ld4(A.ws, node, 5 * d, 2 * d + col);
-        h0 = ld4(A.ws, node, 5 * d, 3 * d + col); hp = ld4(A.ws, node, 5 * d, 4 * d + col);
-      }
+      if (ob + 1 < NB) fetch(ob + 1, nxt);
+      __builtin_amdgcn_sched_barrier(0);
+      const float4 g = cur[0], r = cur[1], z = cur[2], nn = cur[3], h0 = cur[4], hp = cur[5];
       const float gv[4] = {g.x, g.y, g.z, g.w}, rv[4] = {r.x, r.y, r.z, r.w}, zv[4] = {z.x, z.y, z.z, z.w};
       const float nv[4] = {nn.x, nn.y, nn.z, nn.w}, hv[4] = {h0.x, h0.y, h0.z, h0.w}, pv[4] = {hp.x, hp.y, hp.z, hp.w};
       float dr[4], dz[4], dn[4], dnr[4];
@@ -137,7 +148,9 @@ __global__ __launch_bounds__(DB_T, 2) void dense_bwd_kernel(DenseBwdArgs A) {
         acc_dx[o] = mfma4(a2, dn, acc_dx[o]);
         acc_dh[o] = mfma4(b2, dnr, acc_dh[o]);
       }
-      __builtin_amdgcn_sched_barrier(0);      // one block's loads in flight at a time: all four at once do not fit 256 registers
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 6; ++q) cur[q] = nxt[q];
     }
 
     // ---- d h0, dpre (dropout mask, activation derivative) --------------------------------------------------------------
