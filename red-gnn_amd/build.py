@@ -18,8 +18,13 @@ FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
 
+# the files with the most template instances first, so that the longest compile starts at once
+_SLOW_FIRST = ["layer_bwd.hip", "tlayer_bwd.hip", "layer_fwd.hip", "tlayer_fwd.hip", "dense.hip", "dense128.hip", "dense_bwd.hip"]
+
+
 def _sources():
-    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+    srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+    return [f for f in _SLOW_FIRST if f in srcs] + [f for f in srcs if f not in _SLOW_FIRST]
 
 
 def _deps_mtime():
@@ -47,7 +52,7 @@ def build_native(force=False, verbose=False):
     if force:
         for f in os.listdir(OBJ):
             os.remove(os.path.join(OBJ, f))
-    with ThreadPoolExecutor(max_workers=4) as ex:
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 4)) as ex:
         objs = list(ex.map(_compile, _sources()))
     if (not os.path.exists(LIB)) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs):
         cmd = ["hipcc", "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs

@@ -46,7 +46,7 @@ struct BwdArgs {
   float* g_ar;            // [n_rela_rows][ap]
   float* g_w;
   float* g_b;
-  int diag;   // RG_BWD_DIAG (timing experiments only): bit 0 skips dRel entirely, bit 1 uses the in-kernel dRel path
+  int diag;   // RG_BWD_DIAG (timing experiments only): bit 0 skips the relation-major dRel pass
 };
 
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -533,10 +533,6 @@ int launch2(const BwdArgs& A, int B, const rg_vrows& vr, const int2* bm_old, hip
   const size_t rela_bytes = (size_t)A.n_rela_rows * G * sizeof(float4) + (((size_t)A.n_rela_rows * (4 * G + 8) + 3) & ~(size_t)3) * sizeof(float);
   RG_CHECK(lds <= 160 * 1024, "rg_layer_bwd: attention tables need %zu B of LDS (> 160 KiB)", lds);
   const size_t rela_only = (size_t)A.n_rela_rows * G * sizeof(float4);
-  if (A.diag & 2) {   // in-kernel dRel (run-length LDS / global atomics): relation table too big for the separate pass, or RG_BWD_DIAG bit 1
-    if (lds + rela_bytes <= 80 * 1024) return launch3<G, AP4, PACKED, DENSE, true, true>(A, lds + rela_bytes, B, vr, bm_old, s);
-    return launch3<G, AP4, PACKED, DENSE, false, true>(A, lds, B, vr, bm_old, s);
-  }
   // dRel comes from the relation-major pass (drel_kernel); here the rela rows are only read
   if (lds + rela_only <= 80 * 1024) return launch3<G, AP4, PACKED, DENSE, true, false>(A, lds + rela_only + 64, B, vr, bm_old, s);
   return launch3<G, AP4, PACKED, DENSE, false, false>(A, lds, B, vr, bm_old, s);
@@ -618,7 +614,7 @@ extern "C" int rg_layer_bwd(const rg_frontier* f, const rg_graph* g, int32_t lev
   else rc = launch_ap<64>(A, ap / 4, f->B, g->out_vr, bm_old, dense, s);
   if (rc) return rc;
   if (grad_a_q && rg::launch_aq_sum(bm_old, f->W, f->B, f->n_ent, n_old, grad_a_s, ap, grad_a_q, s)) return 1;
-  if (A.diag & 3) return 0;
+  if (A.diag & 1) return 0;
   // relation gradient, relation-major (see drel_kernel)
   DrelArgs D;
   D.walk.n_items = (int64_t)f->B * g->rel_vr.n; D.walk.n_vrows = g->rel_vr.n; D.walk.n_slots = 0; D.walk.vrows = g->rel_vr.rows;
