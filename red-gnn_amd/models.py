@@ -11,9 +11,11 @@ What is different inside (nothing is different outside):
     its adjoint rg_layer_bwd; the three attention Linear layers are hoisted to per-node /
     per-relation / per-query projections (exact re-association, SURVEY.md §9);
   * dense algebra that is not on the E-proportional path (W_h, GRU cell, hoisted projections, W_final): inference runs it
-    in one f32-MFMA kernel per layer (rg_dense_fwd); training keeps it in torch on the device, with the weight gradients
-    of the node-row GEMMs issued in row-chunked batched form (``tall_linear``: a [m,n] = G^T X product over millions of
-    rows otherwise lands on a handful of workgroups).
+    in one f32-MFMA kernel per layer (rg_dense_fwd), and from the third call of a (graph, batch size) on replays the whole
+    forward as one captured HIP graph (_GraphedInference); training runs W_h + act + carry + dropout + GRU step as one kernel
+    too (_DenseStep: rg_dense_train_fwd / rg_dense_train_bwd), with the weight gradients - sums over millions of node rows -
+    issued as row-chunked batched GEMMs (``tall_linear`` / ``_gram_tn``: a plain [m,n] = G^T X product lands on a handful of
+    workgroups).
 """
 import os
 
