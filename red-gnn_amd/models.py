@@ -116,9 +116,10 @@ class _DenseStep(torch.autograd.Function):
     """hidden_new = GRU(dropout(act(agg W_h^T)), h0 carried from the previous frontier)  -  models.py:41,81-83 of one layer.
 
     Forward: one fused f32-MFMA kernel (rg_dense_train_fwd) that also leaves the GRU input and the gate workspace in the layout of
-    PyTorch's fused GRU cell.  Backward: that cell's own fused backward kernel for the gates, row-chunked batched GEMMs for the
-    five weight gradients (_gram_tn), plain GEMMs for the input gradients; the carry's gradient is a gather (every old node is
-    exactly one new node)."""
+    PyTorch's fused GRU cell.  Backward: one fused kernel for everything per node row (rg_dense_train_bwd: gate, input, carry and
+    agg gradients) from _FUSED_BWD_ROWS rows up - below that, and at d = 128, aten's fused GRU-cell backward and three GEMMs -
+    plus row-chunked batched GEMMs for the five weight gradients (_gram_tn); the carry's gradient goes back by a gather (every
+    old node is exactly one new node)."""
 
     @staticmethod
     def forward(ctx, agg, hidden_prev, W_h, w_ih, w_hh, b_ih, b_hh, prev_idx, old_new, mask, act, gate, keep):
