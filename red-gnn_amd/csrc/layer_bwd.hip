@@ -46,6 +46,7 @@ struct BwdArgs {
   float* g_ar;            // [n_rela_rows][ap]
   float* g_w;
   float* g_b;
+  int kpg;    // walk.h: items per lane group of the dense walk (8 on short-row graphs)
   int diag;   // RG_BWD_DIAG (timing experiments only): bit 0 skips the relation-major dRel pass
 };
 
@@ -78,7 +79,8 @@ constexpr int BWD_BLOCK = 512;
 // DREL: accumulate dRel inside this kernel (run-length + LDS atomics).  When false the separate relation-major pass
 // (drel_kernel below) computes it and this kernel only needs rela rows for the attention gradient's dot product.
 // (AP4 >= 4, attn_dim > 12: 4 x AP4 float4 of per-edge attention state; 256 VGPRs instead of spilling at 128)
-template <int G, int AP4, bool PACKED, bool DENSE, bool RELA_LDS, bool DREL>
+// KPG: items per lane group and block step of the dense walk (walk.h): 8 on graphs of short rows, as in the forward
+template <int G, int AP4, bool PACKED, bool DENSE, bool RELA_LDS, bool DREL, int KPG = 1>
 __global__ __launch_bounds__(BWD_BLOCK, AP4 >= 4 ? 2 : 4) void layer_bwd_kernel(BwdArgs A) {
   extern __shared__ float4 lds[];
   constexpr int BLOCK = BWD_BLOCK;
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(BWD_BLOCK, AP4 >= 4 ? 2 : 4) void layer_bwd_kernel(
   for (int k = 0; k < AP4; ++k) gw[k] = f4zero();
   float gb = 0.f;
 
-  rg::walk_items<G, DENSE, 1, BLOCK>(A.walk, recs, [&](const int4& R, bool live) {
+  rg::walk_items<G, DENSE, KPG, BLOCK>(A.walk, recs, [&](const int4& R, bool live) {
     const int beg = R.x, end = R.x + rg::walk_len(R), b = R.z, s_node = R.w;
     float4 base[AP4], gas[AP4];
 #pragma unroll
@@ -508,12 +510,12 @@ __global__ void bwd_combine_kernel(const int4* __restrict__ split, int n_split, 
   else g_as[(int64_t)s * ap4 + (c - ld4)] = acc;
 }
 
-template <int G, int AP4, bool PACKED, bool DENSE, bool RELA_LDS, bool DREL>
+template <int G, int AP4, bool PACKED, bool DENSE, bool RELA_LDS, bool DREL, int KPG = 1>
 int launch3(const BwdArgs& A, size_t lds, int B, const rg_vrows& vr, const int2* bm_old, hipStream_t s) {
-  auto kern = layer_bwd_kernel<G, AP4, PACKED, DENSE, RELA_LDS, DREL>;
+  auto kern = layer_bwd_kernel<G, AP4, PACKED, DENSE, RELA_LDS, DREL, KPG>;
   if (lds > 64 * 1024) RG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int per_cu = lds <= 80 * 1024 ? 2 : 1;
-  const int grid = rg::walk_grid(A.walk.n_items, BWD_BLOCK, G, DENSE, per_cu, 1);
+  const int grid = rg::walk_grid(A.walk.n_items, BWD_BLOCK, G, DENSE, per_cu, KPG);
   if (rg::zero_async(A.walk.queues, 8 * sizeof(int32_t), s)) return 1;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(BWD_BLOCK), lds, s, A);
   RG_LAUNCH_CHECK();
@@ -534,6 +536,13 @@ int launch2(const BwdArgs& A, int B, const rg_vrows& vr, const int2* bm_old, hip
   RG_CHECK(lds <= 160 * 1024, "rg_layer_bwd: attention tables need %zu B of LDS (> 160 KiB)", lds);
   const size_t rela_only = (size_t)A.n_rela_rows * G * sizeof(float4);
   // dRel comes from the relation-major pass (drel_kernel); here the rela rows are only read
+  if constexpr (DENSE) {
+    if (A.kpg > 1) {
+      if (lds + rela_only <= 80 * 1024)
+        return launch3<G, AP4, PACKED, true, true, false, rg::RG_KPG_SHORT>(A, lds + rela_only + 64, B, vr, bm_old, s);
+      return launch3<G, AP4, PACKED, true, false, false, rg::RG_KPG_SHORT>(A, lds, B, vr, bm_old, s);
+    }
+  }
   if (lds + rela_only <= 80 * 1024) return launch3<G, AP4, PACKED, DENSE, true, false>(A, lds + rela_only + 64, B, vr, bm_old, s);
   return launch3<G, AP4, PACKED, DENSE, false, false>(A, lds, B, vr, bm_old, s);
 }
@@ -598,6 +607,7 @@ extern "C" int rg_layer_bwd(const rg_frontier* f, const rg_graph* g, int32_t lev
   A.grad_agg = (const float4*)grad_agg; A.g_hidden = (float4*)grad_hidden; A.g_rela = grad_rela;
   A.g_as = (float4*)grad_a_s; A.g_ar = grad_a_r; A.g_w = grad_w_alpha; A.g_b = grad_b_alpha;
   { const char* e = getenv("RG_BWD_DIAG"); A.diag = e ? atoi(e) : 0; }
+  A.kpg = rg::walk_kpg(g->n_fact, g->out_vr.n);
   A.g_hidden_part = (float4*)scratch;
   A.g_as_part = (float4*)((char*)scratch + rg::align_up((size_t)f->B * g->out_vr.n_slots * ld * sizeof(float), 256));
   hipStream_t s = (hipStream_t)stream;
