@@ -4,13 +4,17 @@ A *step* is one evaluation pass of the hot path over one batch of synthetic quer
 frontier expansion + n_layer fused message-passing layers + GRU/readout + filtered ranking
 (RED_GNN_trans.forward + cal_ranks of the reference).  Workload = BASELINE.json configs[1]:
 synthetic KG 10k entities / 50 relations / 200k triples (seed 1234), n_layer=3, hidden_dim=64,
-attn_dim=5, batch of B queries per GPU.  Queries are sharded over ranks (weak scaling: B per GPU
-fixed); for N>1 scores are all-gathered over RCCL and the 4 metric sums all-reduced.
+attn_dim=5, batch of B queries per GPU.  Queries are sharded over ranks by estimated cost (weak scaling:
+B per GPU fixed); for N>1 scores are all-gathered over RCCL and the 4 metric sums all-reduced.
+After the timed region (never inside it) rank 0 also runs: the second half of the metric's name —
+BaseModel.evaluate on the real family graph (configs[0] shape, n_tbatch=50) — and the CPU baseline,
+whose oracle scores double as an end-to-end parity check at bench size.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--no-cpu-baseline] [--no-family-eval]
 
 Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` for the dominant
-kernel (layer_fwd_kernel, HIP events on its stream) and `cpu_baseline` (the oracle on host cores).
+kernel (the layer_fwd kernels, HIP events on their stream), `roofline_l2` (the roof that binds them once a
+query's rows are L2-resident), `per_hop`, `roofline_dense` and `cpu_baseline` (the oracle on host cores).
 """
 import argparse
 import json
@@ -25,8 +29,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK = 8.0e12      # B/s, /opt/skills/guides/MI355X_MICROARCH.md (spec; ~6.3e12 achievable)
+HBM_PEAK = 8.0e12          # B/s, /opt/skills/guides/MI355X_MICROARCH.md (spec; ~6.3e12 achievable)
+L2_GATHER_PEAK = 18.8e12   # B/s, same guide, "Indexed rows": rows shared by every workgroup served by the XCDs' L2s, 16.8-18.8 TB/s chip-wide
 MFMA_F32_PEAK = 157.3e12   # FLOP/s, same guide: f32-input MFMA = the FP32 vector rate
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic_layer_fwd.json")
 
 
 class Params:
@@ -40,16 +46,74 @@ def algorithmic_bytes(n_edges, n_nodes, d):
     return n_edges * (4 * d + 16) + n_nodes * 4 * d
 
 
-def cpu_baseline(kg, shape, state, subs, rels, ans, filt, budget_s=20.0):
-    """The oracle (CPU restatement, validated against the reference) on the host cores: same KG, same
-    weights, the first queries of the same batch.  Bounded sample: batches of 4 queries until ~budget_s."""
+def stored_traffic(config, batch, version, path=TRAFFIC_FILE):
+    """HBM bytes per layer_fwd launch from the committed PMC passes (tools/pmc_traffic.sh), or None unless an entry matches
+    this exact workload AND kernel version (rg_version): a profile of another shape or of older kernels is not evidence."""
+    try:
+        with open(path) as f:
+            entries = json.load(f).get("entries", [])
+    except (OSError, ValueError):
+        return None
+    for e in entries:
+        if e.get("config") == config and int(e.get("batch", -1)) == int(batch) and int(e.get("rg_version", -1)) == int(version):
+            return e
+    return None
+
+
+def layer_rooflines(events_ms, d, n_layer, traffic_entry=None):
+    """The roofline objects of the message-passing kernel from per-launch records (ms, n_edges, n_nodes), launch i being hop
+    i % n_layer.  Pure arithmetic (tested on the host).
+
+    roofline     the contract's object: ALGORITHMIC bytes (every gathered row counted as if it came from HBM) over
+                 the measured launch time against the HBM peak.  Its frac can exceed 1 because the rows are not HBM traffic.
+    roofline_l2  the roof that binds: gathered row bytes (E * 4d) over the same time against the L2 gather rate; frac <= 1.
+    per_hop      E, N, ms, both fractions per hop (expanding hops sit far below saturated ones)."""
+    n = len(events_ms)
+    if n == 0:
+        return None, None, None
+    tot_ms = sum(ms for ms, _, _ in events_ms)
+    k_bytes = sum(algorithmic_bytes(ne, nn, d) for _, ne, nn in events_ms)
+    k_edges = sum(ne for _, ne, _ in events_ms)
+    achieved = k_bytes / (tot_ms * 1e-3)
+    traffic = traffic_entry["hbm_bytes_per_launch"] if traffic_entry else None
+    roof = dict(bound="hbm", kernel="layer_fwd kernels (walk + word-parallel)", achieved=achieved / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s",
+                frac=achieved / HBM_PEAK, traffic=traffic, launches=n, avg_launch_ms=tot_ms / n,
+                algorithmic_bytes_per_launch=k_bytes / n, kernel_edges_per_s=k_edges / (tot_ms * 1e-3),
+                note="algorithmic bytes count every gathered row as HBM (SURVEY 8d); a query's rows are L2-resident, so see roofline_l2 "
+                     "for the roof that binds and `traffic` / hbm_measured_frac for the bytes that reach memory")
+    if traffic is not None:
+        roof["hbm_measured_frac"] = traffic / (tot_ms / n * 1e-3) / HBM_PEAK
+        roof["traffic_source"] = traffic_entry.get("source")
+    row_bytes = k_edges * 4.0 * d
+    l2 = dict(bound="l2-gather", kernel=roof["kernel"], achieved=row_bytes / (tot_ms * 1e-3) / 1e9, peak=L2_GATHER_PEAK / 1e9, unit="GB/s",
+              frac=row_bytes / (tot_ms * 1e-3) / L2_GATHER_PEAK, bytes="gathered source rows only: E * 4 * d")
+    hops = []
+    for h in range(n_layer):
+        sel = events_ms[h::n_layer]
+        if not sel:
+            continue
+        ms = sum(m for m, _, _ in sel) / len(sel)
+        ne = sum(e for _, e, _ in sel) / len(sel)
+        nn = sum(x for _, _, x in sel) / len(sel)
+        hops.append(dict(hop=h, edges=ne, nodes=nn, ms=ms, edges_per_s=ne / (ms * 1e-3),
+                         hbm_algorithmic_frac=algorithmic_bytes(ne, nn, d) / (ms * 1e-3) / HBM_PEAK,
+                         l2_gather_frac=ne * 4.0 * d / (ms * 1e-3) / L2_GATHER_PEAK))
+    return roof, l2, hops
+
+
+def cpu_baseline(kg, shape, state, subs, rels, ans, filt, gpu_scores, gpu_ranks, ans_ptr, budget_s=20.0, bs=50):
+    """The oracle (CPU restatement, validated against the reference) on the host cores: same KG, same weights, the first
+    queries of the same batch, in batches of 50 as the reference evaluates (train.py:46-56 n_tbatch) until ~budget_s.
+    Its scores are compared with the GPU's for the very same queries: an end-to-end parity check at bench size, for free."""
     from oracle import redgnn_oracle as orc
     n_cpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     torch.set_num_threads(max(1, min(n_cpu, 64)))       # the cores this process may actually run on
     og = orc.OracleGraph(np.concatenate([orc.double_triple(kg.facts, kg.n_rel), orc.double_triple(kg.train, kg.n_rel)], 0),
                          kg.n_ent, kg.n_rel)
     p = {k: v.detach().cpu() for k, v in state.items()}
-    bs, done, edges, t_tot = 4, 0, 0, 0.0
+    bs = min(bs, len(subs))
+    done, edges, t_tot = 0, 0, 0.0
+    scores_ok, max_err, rank_kernel_ok, n_rank, n_rank_same, n_viol, max_abs, f64 = True, 0.0, True, 0, 0, 0, 0.0, None
     while done + bs <= len(subs) and (t_tot < budget_s or done == 0):
         sl = slice(done, done + bs)
         t0 = time.perf_counter()
@@ -59,14 +123,40 @@ def cpu_baseline(kg, shape, state, subs, rels, ans, filt, budget_s=20.0):
         for i in range(bs):
             labels[i, ans[done + i]] = 1
             fl[i, filt[done + i]] = 1
-        orc.cal_ranks(sc, labels, fl)
+        cpu_ranks = np.asarray(orc.cal_ranks(sc, labels, fl))
         t_tot += time.perf_counter() - t0
         edges += sum(len(t["edges"]) for t in trace)
+        # ---- parity at bench size (outside every timed region) ----
+        g = gpu_scores[sl]
+        viol = np.abs(g - sc) > 2e-5 + 1e-4 * np.abs(sc)
+        n_viol += int(viol.sum())
+        scores_ok &= bool(np.array_equal(g == 0, sc == 0))
+        max_err = max(max_err, float(np.max(np.abs(g - sc))))
+        max_abs = max(max_abs, float(np.max(np.abs(sc))))
+        if done == 0:
+            # the reference's fp32 evaluation is itself only so close to the exact value (hub destinations sum thousands of fp32
+            # terms in an unspecified order): the same batch in fp64 says how far each fp32 path is from it
+            s64 = orc.forward(p, og, subs[sl], rels[sl], shape["n_layer"], act="relu", dtype=torch.float64).numpy()
+            f64 = dict(gpu_max_err_vs_fp64=float(np.max(np.abs(g - s64))), cpu_fp32_max_err_vs_fp64=float(np.max(np.abs(sc - s64))),
+                       gpu_violations_vs_fp64=int(np.sum(np.abs(g - s64) > 2e-5 + 1e-4 * np.abs(s64))), queries=bs)
+        g_ranks = gpu_ranks[ans_ptr[done]:ans_ptr[done + bs]]
+        rank_kernel_ok &= bool(np.array_equal(g_ranks, np.asarray(orc.cal_ranks(g, labels, fl))))     # rg_rank on the GPU's own scores
+        n_rank += len(cpu_ranks)
+        n_rank_same += int(np.sum(g_ranks == cpu_ranks))                                               # vs the CPU path end to end
         done += bs
     return dict(value=edges / t_tot, unit="edges/s", cores=torch.get_num_threads(), kind="port",
-                sample="%d of the batch's queries (batches of %d), same KG and weights, forward + cal_ranks, %.1f s; %.1f queries/s"
-                       % (done, bs, t_tot, done / t_tot),
-                queries_per_s=done / t_tot)
+                sample="%d of the batch's queries (batches of %d, the reference's n_tbatch), same KG and weights, forward + cal_ranks, "
+                       "%.1f s; %.1f queries/s" % (done, bs, t_tot, done / t_tot),
+                queries_per_s=done / t_tot), \
+        {"parity_at_bench_size": bool(scores_ok and rank_kernel_ok and
+                                      (n_viol == 0 or f64["gpu_max_err_vs_fp64"] <= max(4.0 * f64["cpu_fp32_max_err_vs_fp64"], 2e-5))),
+         "criterion": "zero pattern equal; every score within rtol 1e-4 / atol 2e-5 of the CPU path, or the GPU's max error against the "
+                      "fp64 evaluation of the same batch <= 4x the CPU fp32 path's own; rg_rank on the GPU's scores == the oracle's ranking of them",
+         "queries_checked": done, "zero_pattern_equal": bool(scores_ok), "rtol": 1e-4, "atol": 2e-5,
+         "elements_beyond_rtol_atol_of_cpu_fp32": n_viol, "elements": done * kg.n_ent, "max_abs_score_err": max_err, "max_abs_score": max_abs,
+         "fp64_check_first_batch": f64,
+         "rank_kernel_equals_oracle_ranking_of_gpu_scores": bool(rank_kernel_ok),
+         "ranks_identical_to_cpu_path": "%d of %d" % (n_rank_same, n_rank)}
 
 
 def family_eval(dist, world, engine):
@@ -95,7 +185,7 @@ def family_eval(dist, world, engine):
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        reps = 3
+        reps = 5
         for _ in range(reps):
             mrr, _ = bm.evaluate()
         if dist is not None:
@@ -116,14 +206,15 @@ def family_eval(dist, world, engine):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=1024, help="queries per GPU per step")
     ap.add_argument("--config", default="C2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
-    ap.add_argument("--family-eval", action="store_true", help="also time BaseModel.evaluate on the real family graph (n_tbatch=50, graph replay); "
-                    "off by default so that a rocprofv3 run of the default command sees the C2 step's kernels only")
+    ap.add_argument("--no-family-eval", action="store_true", help="skip BaseModel.evaluate on the real family graph (runs after the timed region "
+                    "by default); for rocprofv3 runs that should see the C2 step's kernels only")
+    ap.add_argument("--family-eval", action="store_true", help=argparse.SUPPRESS)     # (the default since round 2; kept for old command lines)
     ap.add_argument("--graphs", action="store_true", help="replay the forward as a captured HIP graph (no per-kernel HIP events, so no roofline object)")
     ap.add_argument("--backend", default="nccl", help="process-group backend: nccl (= RCCL; one GPU per rank) or gloo (rehearsal of the "
                     "N > 1 path with several ranks sharing one GPU)")
@@ -149,10 +240,10 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
-    from red_gnn_amd import engine
+    from red_gnn_amd import _lib, engine
     from red_gnn_amd.load_data import DataLoader
     from red_gnn_amd.models import RED_GNN_trans
-    from red_gnn_amd.sharding import shard_slice, gather_scores, reduce_metrics
+    from red_gnn_amd.sharding import gather_scores, query_costs, reduce_metrics, shard_balanced
     from red_gnn_amd.synthetic import SHAPES, make_shape
     from red_gnn_amd.utils import cal_ranks_csr
 
@@ -167,8 +258,14 @@ def main():
 
     B = args.batch
     n_q = loader.n_test
-    lo, hi = shard_slice(B * world, world, rank)              # this rank's queries of the global batch
-    q_idx = np.arange(lo, hi) % n_q
+    glob = np.arange(B * world) % n_q                        # the global batch: the first B * world test queries
+    if world > 1:
+        # per-query subgraphs differ by far more than 2x (hub subjects): deal the queries by estimated cost, equal counts per rank
+        costs = query_costs(loader._tgraph_base, kg.n_ent, np.array([loader.test_q[i][0] for i in glob]))
+        mine = np.asarray(shard_balanced(costs, world)[rank])
+    else:
+        mine = np.arange(B)
+    q_idx = glob[mine]
     subs, rels, a_ptr, a_idx, f_ptr, f_idx = loader.get_batch_csr(q_idx, data="test")
 
     kernel_events, dense_events = [], []
@@ -177,6 +274,7 @@ def main():
         engine.DENSE_EVENTS = dense_events
 
     pending = []     # the previous step's all-gather (RCCL stream): it overlaps the next step's kernels
+    last = {}
 
     def step():
         with torch.no_grad():
@@ -190,6 +288,7 @@ def main():
                 # north star: RCCL all-gather of the score shards over xGMI; asynchronous, joined one step later
                 pending.append(gather_scores(scores, dist, async_op=True) + (scores,))
                 sums = reduce_metrics(sums, dist)
+            last["scores"], last["ranks"] = scores, ranks
         return sums, model.last_stats
 
     if args.graphs:
@@ -220,42 +319,35 @@ def main():
         dt, edges = float(tmax[0]), float(tsum[1])
     total_edges = float(edges)
 
-    family = family_eval(dist, world, engine) if args.family_eval else None      # second half of the metric's name
+    # per-launch records before anything else touches the event lists
+    ev_ms = [(e0.elapsed_time(e1), ne, nn) for (e0, e1, ne, nn) in kernel_events]
+    dense_ms = [(e0.elapsed_time(e1), n) for (e0, e1, n) in dense_events]
+    gpu_scores = last["scores"].cpu().numpy() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+    gpu_ranks = last["ranks"].double().cpu().numpy() if gpu_scores is not None else None
+
+    # second half of the metric's name, after (never inside) the timed region
+    family = None if args.no_family_eval else family_eval(dist, world, engine)
 
     if rank == 0:
-        # dominant kernel: layer_fwd_kernel (HIP events recorded around every launch of the timed steps)
-        roof = None
-        if kernel_events:
-            k_ms = sum(e0.elapsed_time(e1) for (e0, e1, _, _) in kernel_events)
-            k_bytes = sum(algorithmic_bytes(ne, nn, d) for (_, _, ne, nn) in kernel_events)
-            k_edges = sum(ne for (_, _, ne, _) in kernel_events)
-            n_launch = len(kernel_events)
-            achieved = k_bytes / (k_ms * 1e-3)
-            traffic = None
-            prof = os.path.join(ROOT, "profiles", "traffic_layer_fwd.json")
-            if os.path.exists(prof):
-                with open(prof) as f:
-                    traffic = json.load(f).get("hbm_bytes_per_launch")
-            roof = dict(bound="hbm", kernel="layer_fwd_kernel", achieved=achieved / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s",
-                        frac=achieved / HBM_PEAK, traffic=traffic, launches=n_launch,
-                        avg_launch_ms=k_ms / n_launch, algorithmic_bytes_per_launch=k_bytes / n_launch,
-                        kernel_edges_per_s=k_edges / (k_ms * 1e-3))
+        version = int(_lib.lib().rg_version())
+        roof, roof_l2, per_hop = layer_rooflines(ev_ms, d, shape["n_layer"], stored_traffic(args.config, B, version))
         roof_dense = None
-        if dense_events:
+        if dense_ms:
             # second kernel of the step: W_h + GRU + projections on f32 MFMA.  Algorithmic flops per node (what the
             # reference computes): 2*d*d*(1 + 3 + 3) for W_h, weight_ih, weight_hh, + 2*d*attn_dim for the hoisted Ws_attn
-            d_ms = sum(e0.elapsed_time(e1) for (e0, e1, _) in dense_events)
-            rows = sum(n for (_, _, n) in dense_events)
+            d_ms = sum(m for m, _ in dense_ms)
+            rows = sum(n for _, n in dense_ms)
             flops = rows * (2.0 * d * d * 7 + 2.0 * d * shape["attn_dim"])
             roof_dense = dict(bound="mfma", kernel="dense_kernel", achieved=flops / (d_ms * 1e-3) / 1e12, peak=MFMA_F32_PEAK / 1e12,
-                              unit="TFLOP/s", frac=flops / (d_ms * 1e-3) / MFMA_F32_PEAK, traffic=None, launches=len(dense_events),
-                              avg_launch_ms=d_ms / len(dense_events), algorithmic_flops_per_launch=flops / len(dense_events))
-        cpu = None
-        if world == 1 and not args.no_cpu_baseline:
+                              unit="TFLOP/s", frac=flops / (d_ms * 1e-3) / MFMA_F32_PEAK, traffic=None, launches=len(dense_ms),
+                              avg_launch_ms=d_ms / len(dense_ms), algorithmic_flops_per_launch=flops / len(dense_ms))
+        cpu = parity = None
+        if gpu_scores is not None:
             query, answer = loader.test_q, loader.test_a
             ans = [np.asarray(answer[i]) for i in q_idx]
             filt = [np.asarray(loader.filters[(int(s), int(r))]) for s, r in zip(subs, rels)]
-            cpu = cpu_baseline(kg, shape, model.state_dict(), np.asarray(subs), np.asarray(rels), ans, filt)
+            cpu, parity = cpu_baseline(kg, shape, model.state_dict(), np.asarray(subs), np.asarray(rels), ans, filt, gpu_scores, gpu_ranks,
+                                       a_ptr.cpu().numpy())
         s = sums.double().cpu().numpy()
         out = {
             "metric": "edges aggregated/sec + MRR-eval queries/sec, family KG n_layer=3 at 1/2/4/8 GPU",
@@ -265,11 +357,15 @@ def main():
             "config": {"workload": "%s synthetic KG %d entities / %d relations / %d triples (seed 1234), n_layer=%d hidden_dim=%d attn_dim=%d, "
                                    "eval step = expansion + fused layers + GRU/readout + filtered ranking, %d queries per GPU"
                                    % (args.config, kg.n_ent, kg.n_rel, shape["n_triples"], shape["n_layer"], d, shape["attn_dim"], B),
-                       "batch_per_gpu": B, "global_batch": B * world, "sharding": ("queries over ranks, scores all-gathered (%s)" % ("RCCL" if args.backend == "nccl" else args.backend)) if world > 1 else "none"},
+                       "batch_per_gpu": B, "global_batch": B * world,
+                       "sharding": ("queries dealt over ranks by estimated cost (equal counts), scores all-gathered (%s)"
+                                    % ("RCCL" if args.backend == "nccl" else args.backend + ", not RCCL")) if world > 1 else "none"},
             "eval_queries_per_s": B * world * args.steps / dt,
             "edges_per_step": total_edges / args.steps,
             "mrr_of_random_init": float(s[0] / s[3]),
-            "roofline": roof, "roofline_dense": roof_dense, "cpu_baseline": cpu, "family_eval": family,
+            "family_eval_queries_per_s": family["queries_per_s"] if family else None,
+            "roofline": roof, "roofline_l2": roof_l2, "per_hop": per_hop, "roofline_dense": roof_dense, "cpu_baseline": cpu,
+            "parity": parity, "family_eval": family, "rg_version": version,
         }
         print(json.dumps(out))
     if dist is not None:

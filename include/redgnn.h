@@ -112,13 +112,24 @@ int rg_frontier_edges(const rg_frontier* f, const rg_graph* g, int32_t level,
  * hidden [N_old, ld], rela [2R+1, ld], agg_out [N_new, ld] (every row is written);
  * ld % 4 == 0, ld >= d, pad columns of hidden/rela must be zero.  n_new is checked against the
  * frontier.  scratch: device memory of rg_layer_fwd_scratch_bytes() bytes (partial sums of hub
- * destinations that are cut into segments), 16-B aligned. */
+ * destinations that are cut into segments), 16-B aligned.
+ *
+ * walk: how the edges are enumerated (the sums and their order are the same; results are bitwise equal):
+ *   0  let the library pick from the sizes of the hop (known on the host after rg_frontier_expand);
+ *   1  per-query walk: every live destination tests its KG in-edges against the previous frontier;
+ *   2, 3, 4  word-parallel walk for hops whose SOURCE frontier is sparse (as the reference expands from the frontier's
+ *      nodes, load_data.py:115-118): 32 / 16 / 8 queries per work item straight from the entity-major bitmaps; only for
+ *      level == the newest hop of a static graph.
+ * rg_layer_fwd_plan returns what walk 0 would pick for given sizes (n_old, n_new nodes, n_edges of the hop): callers that
+ * enqueue without read-backs (rg_frontier_expand_async) record it from an eager run and pass it explicitly. */
 size_t rg_layer_fwd_scratch_bytes(const rg_frontier* f, const rg_graph* g, int32_t ld);
+int rg_layer_fwd_plan(const rg_frontier* f, const rg_graph* g, int32_t level, int64_t n_old, int64_t n_new,
+                      int64_t n_edges, int32_t ld);
 int rg_layer_fwd(const rg_frontier* f, const rg_graph* g, int32_t level, int64_t n_new,
                  const float* hidden, const float* rela, int32_t d, int32_t ld,
                  const float* a_s, const float* a_r, const float* a_q, int32_t ap,
                  const float* w_alpha, const float* b_alpha, int32_t attn_dim,
-                 float* agg_out, void* scratch_dev, size_t scratch_bytes, void* stream);
+                 float* agg_out, void* scratch_dev, size_t scratch_bytes, int32_t walk, void* stream);
 
 /* ---- temporal layer forward: replaces Temporal/interpolation/model_cuda.py:149-160,192 ------------------
  * agg[o] = sum_e alpha_e * (hidden_dir[3 s + dir_e] + rela_dir[dir_e * n_rela_rows + r] + time_dir[dir_e * n_time + |dt_e|]),

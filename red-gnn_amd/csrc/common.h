@@ -64,6 +64,20 @@ struct rg_vrows {
   int4* split = nullptr;
 };
 
+// Packs of the word-parallel forward walk (layer_fwd_wp.hip): the virtual rows of the CSR-by-tail bin-packed into groups of
+// RG_PACK entries, so that one wave covers a pack with RG_PACK/64 entries per lane and takes 32 queries at a time from the
+// entity-major frontier bitmaps.  ent[p*RG_PACK + e] = {packed (rel << 20 | head) or -1 (padding), index of the entry's row
+// inside the pack}; rows of a pack are contiguous in e, in CSR order.  pack[p] = {first row in `rows`, number of rows, slot of
+// the partial sum if the pack is one segment of a cut row (then it is the pack's only row) else -1, that row's entity};
+// rows[] = {entity, slot or -1}.
+constexpr int RG_PACK = 128;
+struct rg_packs {
+  int32_t n = 0;
+  int2* ent = nullptr;
+  int4* pack = nullptr;
+  int2* rows = nullptr;
+};
+
 struct rg_graph {
   void* arena = nullptr;     // the one device allocation all arrays below are slices of
   int32_t n_ent = 0, n_rel = 0;
@@ -84,6 +98,7 @@ struct rg_graph {
   uint32_t* in_pk = nullptr;
   uint32_t* out_pk = nullptr;   // same packing for the CSR-by-head: (rel << 20 | tail)
   rg_vrows in_vr, out_vr;
+  rg_packs in_pk_packs;         // static graphs with packed entries only (n = 0 otherwise)
   // CSR by relation (rows = relation ids): rel_ht[n_fact] = {head, tail}; its virtual rows carry the relation id in the
   // entity field.  Used by the backward's relation-gradient pass (one partial row per 128 edges instead of per edge).
   int32_t* rel_ptr = nullptr;

@@ -199,6 +199,42 @@ static void host_vrows(const std::vector<int32_t>& ptr, int32_t n_ent, HostVrows
   out->n = (int32_t)rows.size(); out->n_split = (int32_t)split.size(); out->n_slots = slots;
 }
 
+// bin-pack the virtual rows of the CSR-by-tail into packs of RG_PACK entries (see common.h): best fit over the rows in
+// descending length; a segment of a cut row keeps a pack to itself (the kernel zero-fills its partial sum when it is empty)
+struct HostPacks { std::vector<int2> ent; std::vector<int4> pack; std::vector<int2> rows; };
+static void host_packs(const std::vector<int4>& vrows, const std::vector<uint32_t>& in_pk, HostPacks* hp, rg_packs* out) {
+  std::vector<std::vector<int32_t>> members;            // row indices per pack
+  std::vector<int32_t> open_by_room[RG_PACK + 1];       // packs with exactly that much room left
+  for (int32_t i = 0; i < (int32_t)vrows.size(); ++i) {
+    const int4& r = vrows[i];
+    if (r.z <= 0) continue;
+    if (r.w >= 0) { members.push_back({i}); continue; }
+    int room = r.z;
+    while (room <= RG_PACK && open_by_room[room].empty()) ++room;
+    int32_t p;
+    if (room > RG_PACK) { p = (int32_t)members.size(); members.emplace_back(); room = RG_PACK; }
+    else { p = open_by_room[room].back(); open_by_room[room].pop_back(); }
+    members[p].push_back(i);
+    if (room - r.z > 0) open_by_room[room - r.z].push_back(p);
+  }
+  const size_t n = members.size();
+  hp->ent.assign(n * RG_PACK, make_int2(-1, 0));
+  hp->pack.resize(n);
+  for (size_t p = 0; p < n; ++p) {
+    const int32_t first = (int32_t)hp->rows.size();
+    int32_t e = 0, k = 0;
+    for (int32_t i : members[p]) {
+      const int4& r = vrows[i];
+      for (int32_t j = 0; j < r.z; ++j) hp->ent[p * RG_PACK + e++] = make_int2((int32_t)in_pk[r.y + j], k);
+      hp->rows.push_back(make_int2(r.x, r.w));
+      ++k;
+    }
+    const int4& r0 = vrows[members[p][0]];
+    hp->pack[p] = make_int4(first, k, r0.w, r0.x);
+  }
+  out->n = (int32_t)n;
+}
+
 // One device allocation per graph: every array is a slice of it, filled by one host-to-device copy.  (Two dozen hipMalloc /
 // hipMemcpy pairs - and as many synchronising hipFree calls on destruction - were most of the cost of building a graph, which
 // temporal training does once per batch.)
@@ -217,7 +253,7 @@ struct Arena {
 extern "C" {
 
 const char* rg_last_error(void) { return rg::g_err.c_str(); }
-int rg_version(void) { return 1; }
+int rg_version(void) { return 2; }   // bumped whenever a kernel on the bench path changes: keys profiles/traffic_layer_fwd.json
 
 // rows (H, R, T [, TIME]) -> device CSRs, packed entries, virtual rows
 static int build_graph(int32_t n_ent, int32_t n_rel, int32_t n_rela_rows, const std::vector<int32_t>& H,
@@ -312,6 +348,11 @@ static int build_graph(int32_t n_ent, int32_t n_rel, int32_t n_rela_rows, const 
   A.add(&g->in_vr.rows, hv_in.rows); A.add(&g->in_vr.split, hv_in.split);
   A.add(&g->out_vr.rows, hv_out.rows); A.add(&g->out_vr.split, hv_out.split);
   A.add(&g->rel_vr.rows, hv_rel.rows); A.add(&g->rel_vr.split, hv_rel.split);
+  HostPacks hp;
+  if (!TIME && !in_pk.empty() && n_rela_rows < (1 << 12)) {    // (rel 4095 | head 2^20-1 would read as the padding entry -1)      // (the temporal layer kernel has no word-parallel form; its graphs are rebuilt per batch)
+    host_packs(hv_in.rows, in_pk, &hp, &g->in_pk_packs);
+    A.add(&g->in_pk_packs.ent, hp.ent); A.add(&g->in_pk_packs.pack, hp.pack); A.add(&g->in_pk_packs.rows, hp.rows);
+  }
 
   std::vector<char> staging(A.total);
   for (const Arena::Item& it : A.items)

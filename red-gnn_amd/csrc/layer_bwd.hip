@@ -47,7 +47,6 @@ struct BwdArgs {
   float* g_w;
   float* g_b;
   int kpg;    // walk.h: items per lane group of the dense walk (8 on short-row graphs)
-  int diag;   // RG_BWD_DIAG (timing experiments only): bit 0 skips the relation-major dRel pass
 };
 
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -145,7 +144,7 @@ __global__ __launch_bounds__(BWD_BLOCK, AP4 >= 4 ? 2 : 4) void layer_bwd_kernel(
     int run_r = -1;
     float4 racc = f4zero();
     auto flush_run = [&]() {
-      if (DREL && run_r >= 0 && row_lane && !(A.diag & 1)) {
+      if (DREL && run_r >= 0 && row_lane) {
         if constexpr (RELA_LDS) {
           float* gr = grela_l + run_r * RS + lane_g;
           atomicAdd(gr, racc.x); atomicAdd(gr + G, racc.y); atomicAdd(gr + 2 * G, racc.z); atomicAdd(gr + 3 * G, racc.w);
@@ -606,7 +605,6 @@ extern "C" int rg_layer_bwd(const rg_frontier* f, const rg_graph* g, int32_t lev
   A.n_rela_rows = g->n_rela_rows;
   A.grad_agg = (const float4*)grad_agg; A.g_hidden = (float4*)grad_hidden; A.g_rela = grad_rela;
   A.g_as = (float4*)grad_a_s; A.g_ar = grad_a_r; A.g_w = grad_w_alpha; A.g_b = grad_b_alpha;
-  { const char* e = getenv("RG_BWD_DIAG"); A.diag = e ? atoi(e) : 0; }
   A.kpg = rg::walk_kpg(g->n_fact, g->out_vr.n);
   A.g_hidden_part = (float4*)scratch;
   A.g_as_part = (float4*)((char*)scratch + rg::align_up((size_t)f->B * g->out_vr.n_slots * ld * sizeof(float), 256));
@@ -624,7 +622,6 @@ extern "C" int rg_layer_bwd(const rg_frontier* f, const rg_graph* g, int32_t lev
   else rc = launch_ap<64>(A, ap / 4, f->B, g->out_vr, bm_old, dense, s);
   if (rc) return rc;
   if (grad_a_q && rg::launch_aq_sum(bm_old, f->W, f->B, f->n_ent, n_old, grad_a_s, ap, grad_a_q, s)) return 1;
-  if (A.diag & 1) return 0;
   // relation gradient, relation-major (see drel_kernel)
   DrelArgs D;
   D.walk.n_items = (int64_t)f->B * g->rel_vr.n; D.walk.n_vrows = g->rel_vr.n; D.walk.n_slots = 0; D.walk.vrows = g->rel_vr.rows;

@@ -225,6 +225,16 @@ __global__ void combine_kernel(const int4* __restrict__ split, int n_split, int 
   agg[(int64_t)o * ld4 + c] = acc;
 }
 
+inline int launch_combine(const FwdArgs& A, int B, const rg_vrows& vr, hipStream_t s) {
+  if (vr.n_split > 0) {
+    const int64_t threads = (int64_t)B * vr.n_split * A.ld4;
+    hipLaunchKernelGGL(combine_kernel, dim3(rg::ceil_div(threads, 256)), dim3(256), 0, s, vr.split, vr.n_split, vr.n_slots, B,
+                       A.bm_new, A.W, A.partial, A.agg, A.ld4);
+    RG_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
 template <int G, int AP4, bool PACKED, bool DENSE, int KPG, bool RELA_LDS, bool TEMPORAL>
 int launch3(const FwdArgs& A, size_t lds, int B, const rg_vrows& vr, hipStream_t s) {
   constexpr int BLOCK = FWD_BLOCK;
@@ -235,13 +245,7 @@ int launch3(const FwdArgs& A, size_t lds, int B, const rg_vrows& vr, hipStream_t
   if (rg::zero_async(A.walk.queues, 8 * sizeof(int32_t), s)) return 1;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds, s, A);
   RG_LAUNCH_CHECK();
-  if (vr.n_split > 0) {
-    const int64_t threads = (int64_t)B * vr.n_split * A.ld4;
-    hipLaunchKernelGGL(combine_kernel, dim3(rg::ceil_div(threads, 256)), dim3(256), 0, s, vr.split, vr.n_split, vr.n_slots, B,
-                       A.bm_new, A.W, A.partial, A.agg, A.ld4);
-    RG_LAUNCH_CHECK();
-  }
-  return 0;
+  return launch_combine(A, B, vr, s);
 }
 
 template <int G, int AP4, bool PACKED, bool DENSE, int KPG, bool TEMPORAL>

@@ -11,6 +11,10 @@ import torch
 from . import _lib
 
 
+# tests set this to 1 (per-query walk) or 2..4 (word-parallel, 32/16/8 queries per item) to force rg_layer_fwd's edge walk; 0 = the
+# library picks from the hop's sizes
+FORCE_WALK = 0
+
 # bench.py sets these to lists to collect (start_event, end_event, n_edges, n_new) per rg_layer_fwd launch and
 # (start_event, end_event, n_rows) per rg_dense_fwd launch
 KERNEL_EVENTS = None
@@ -108,12 +112,15 @@ class Frontier:
         self._counts = (C.c_int64 * 4)()
         self.level = -1
         self.n_new = self.n_old = self.n_edges = 0
+        self.generation = 0      # bumped by every reset: the level bitmaps of an older generation are gone
+        self.leases = 0          # live FrontierLease objects (autograd graphs whose backward still reads the level bitmaps)
 
     def reset(self, q_sub):
         """Level 0 = {(b, q_sub[b])} (models.py:73).  q_sub: int32 device tensor [batch]."""
         assert q_sub.dtype == torch.int32 and q_sub.is_cuda and q_sub.numel() == self.batch
         _lib.check(_lib.lib().rg_frontier_reset(self.handle, _lib.ptr(q_sub), _lib.stream_ptr()))
         self.level, self.n_new, self.n_old, self.n_edges = 0, self.batch, 0, 0
+        self.generation += 1
 
     def reset_nodes(self, nodes):
         """Level 0 = an arbitrary node set, int32 device tensor [n,2] (batch, entity)."""
@@ -121,6 +128,7 @@ class Frontier:
         nodes = nodes.contiguous()
         _lib.check(_lib.lib().rg_frontier_reset_nodes(self.handle, _lib.ptr(nodes), nodes.shape[0], _lib.stream_ptr()))
         self.level, self.n_new, self.n_old, self.n_edges = 0, nodes.shape[0], 0, 0
+        self.generation += 1
 
     def expand(self, graph):
         """One hop.  Returns (n_new, n_edges, n_old); synchronises the stream once."""
@@ -195,6 +203,59 @@ class Frontier:
             pass
 
 
+class FrontierLease:
+    """Held by the autograd contexts of one grad-enabled forward: while it lives, the frontier's level bitmaps are still
+    needed by that graph's backward (rg_layer_bwd / rg_tlayer_bwd revisit every hop), so the per-shape caches hand out another
+    Frontier instead of resetting this one (two forwards before the first backward: gradient accumulation, two losses).
+    ``check()`` in backward turns any remaining misuse (a reset behind the lease's back) into a clear error."""
+    __slots__ = ("frontier", "generation", "released")
+
+    def __init__(self, frontier):
+        self.frontier, self.generation, self.released = frontier, frontier.generation, False
+        frontier.leases += 1
+
+    def release(self):
+        """Called when the first hop's backward has run (the last one of a backward pass): autograd frees saved tensors then, but
+        keeps the contexts - and this object - for as long as the forward's output tensor lives.  A second backward through a
+        retained graph is still guarded by check()."""
+        if not self.released:
+            self.released = True
+            self.frontier.leases -= 1
+
+    def check(self):
+        if self.frontier.generation != self.generation:
+            raise RuntimeError("red_gnn_amd: the frontier of this autograd graph was reset by a later forward (generation %d, now %d); "
+                               "its level bitmaps are gone, the backward cannot run" % (self.generation, self.frontier.generation))
+
+    def __del__(self):
+        self.release()
+
+
+class FrontierPool:
+    """Frontiers per shape key; ``get`` returns one that no live autograd graph leases (allocating another if needed)."""
+
+    def __init__(self, max_keys=8):
+        self.max_keys, self.pool = max_keys, {}
+
+    def get(self, n_ent, batch, n_levels, device):
+        key = (n_ent, batch, n_levels, str(device))
+        frs = self.pool.get(key)
+        if frs is None:
+            if len(self.pool) >= self.max_keys:
+                self.pool = {k: [f for f in v if f.leases > 0] for k, v in self.pool.items()}
+                self.pool = {k: v for k, v in self.pool.items() if v}
+            frs = self.pool[key] = []
+        for fr in frs:
+            if fr.leases == 0:
+                return fr
+        fr = Frontier(n_ent, batch, n_levels, device)
+        frs.append(fr)
+        return fr
+
+    def clear(self):
+        self.pool = {}
+
+
 def layer_fwd(frontier, graph, level, nodes_new, hidden, rela, d, a_s, a_r, a_q, w_alpha, b_alpha, attn_dim):
     """agg [n_new, ld] = fused message passing of hop level-1 -> level (rg_layer_fwd)."""
     ld, ap = hidden.shape[1], a_s.shape[1]
@@ -212,24 +273,30 @@ def layer_fwd(frontier, graph, level, nodes_new, hidden, rela, d, a_s, a_r, a_q,
     _lib.check(_lib.lib().rg_layer_fwd(frontier.handle, graph.handle, level, n_new,
                                        _lib.ptr(hidden), _lib.ptr(rela), d, ld, _lib.ptr(a_s), _lib.ptr(a_r),
                                        _lib.ptr(a_q), ap, _lib.ptr(w_alpha), _lib.ptr(b_alpha), attn_dim,
-                                       _lib.ptr(agg), _lib.ptr(scratch), nbytes, _lib.stream_ptr()))
+                                       _lib.ptr(agg), _lib.ptr(scratch), nbytes, FORCE_WALK, _lib.stream_ptr()))
     if ev is not None:
         ev[1].record()
         KERNEL_EVENTS.append((ev[0], ev[1], frontier.n_edges, n_new))
     return agg
 
 
+def layer_fwd_plan(frontier, graph, level, n_old, n_new, n_edges, ld):
+    """The walk rg_layer_fwd picks for a hop of these sizes (rg_layer_fwd_plan): recorded from an eager forward for graph replay."""
+    return int(_lib.lib().rg_layer_fwd_plan(frontier.handle, graph.handle, level, n_old, n_new, n_edges, ld))
+
+
 def layer_fwd_scratch_bytes(frontier, graph, ld):
     return _lib.lib().rg_layer_fwd_scratch_bytes(frontier.handle, graph.handle, ld)
 
 
-def layer_fwd_into(frontier, graph, level, n_hint, hidden, rela, d, a_s, a_r, a_q, w_alpha, b_alpha, attn_dim, agg, scratch):
-    """rg_layer_fwd after expand_async: agg has room for batch * n_ent rows, n_hint (> 0) only picks the walk."""
+def layer_fwd_into(frontier, graph, level, n_hint, hidden, rela, d, a_s, a_r, a_q, w_alpha, b_alpha, attn_dim, agg, scratch, walk=1):
+    """rg_layer_fwd after expand_async: agg has room for batch * n_ent rows; the sizes are not known on the host, so the caller
+    names the walk (recorded from an eager forward of the same shape) and n_hint (> 0) picks the per-query walk's flavour."""
     ld, ap = hidden.shape[1], a_s.shape[1]
     _lib.check(_lib.lib().rg_layer_fwd(frontier.handle, graph.handle, level, max(int(n_hint), 1),
                                        _lib.ptr(hidden), _lib.ptr(rela), d, ld, _lib.ptr(a_s), _lib.ptr(a_r),
                                        _lib.ptr(a_q), ap, _lib.ptr(w_alpha), _lib.ptr(b_alpha), attn_dim,
-                                       _lib.ptr(agg), _lib.ptr(scratch), scratch.numel(), _lib.stream_ptr()))
+                                       _lib.ptr(agg), _lib.ptr(scratch), scratch.numel(), FORCE_WALK or max(int(walk), 1), _lib.stream_ptr()))
 
 
 def tlayer_fwd(frontier, graph, level, n_new, q_time, hidden_dir, rela_dir, time_dir, d, a_s, a_r, a_q, w_alpha, b_alpha, attn_dim):

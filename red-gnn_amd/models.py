@@ -31,6 +31,14 @@ def _pad4(n):
     return (n + 3) // 4 * 4
 
 
+def pad_attn(a):
+    """Padded attention width the layer kernels are instantiated for: multiples of 4 up to 16, then 32 (attn_dim 17..32, e.g. the
+    temporal presets' 30).  The reference accepts any attn_dim (models.py:16-19); wider than 32 has no kernel here."""
+    if a > 32:
+        raise ValueError("attn_dim=%d: the HIP layer kernels cover attention widths up to 32" % a)
+    return _pad4(a) if a <= 16 else 32
+
+
 _FUSED_BWD_ROWS = 1 << 13   # below this the fused dense adjoint's prologue (three transposed weight images per workgroup) costs
                             # more than aten's GRU-cell backward and three small GEMMs
 _TALL_ROWS = 1 << 15        # below this a plain GEMM is as good
@@ -95,20 +103,24 @@ class _Aggregate(torch.autograd.Function):
     """agg = rg_layer_fwd(...);  backward = rg_layer_bwd(...)."""
 
     @staticmethod
-    def forward(ctx, hidden, rela, a_s, a_r, a_q, w_alpha, b_alpha, frontier, graph, level, nodes_new, nodes_old, d, attn_dim):
+    def forward(ctx, hidden, rela, a_s, a_r, a_q, w_alpha, b_alpha, lease, graph, level, nodes_new, nodes_old, d, attn_dim):
         hidden, rela, a_s, a_r, a_q = (t.contiguous() for t in (hidden, rela, a_s, a_r, a_q))
         w_alpha, b_alpha = w_alpha.contiguous(), b_alpha.contiguous()
+        frontier = lease.frontier
         agg = engine.layer_fwd(frontier, graph, level, nodes_new, hidden, rela, d, a_s, a_r, a_q, w_alpha, b_alpha, attn_dim)
         ctx.save_for_backward(hidden, rela, a_s, a_r, a_q, w_alpha, b_alpha, nodes_old)
-        ctx.misc = (frontier, graph, level, d, attn_dim)
+        ctx.misc = (lease, graph, level, d, attn_dim)      # the lease keeps the frontier's level bitmaps for this graph's backward
         return agg
 
     @staticmethod
     def backward(ctx, grad_agg):
         hidden, rela, a_s, a_r, a_q, w_alpha, b_alpha, nodes_old = ctx.saved_tensors
-        frontier, graph, level, d, attn_dim = ctx.misc
+        lease, graph, level, d, attn_dim = ctx.misc
+        lease.check()
         g_h, g_rela, g_as, g_ar, g_aq, g_w, g_b = engine.layer_bwd(
-            frontier, graph, level, nodes_old, hidden, rela, d, a_s, a_r, a_q, w_alpha, b_alpha, attn_dim, grad_agg)
+            lease.frontier, graph, level, nodes_old, hidden, rela, d, a_s, a_r, a_q, w_alpha, b_alpha, attn_dim, grad_agg)
+        if level == 1:
+            lease.release()
         return g_h, g_rela, g_as, g_ar, g_aq, g_w.view_as(w_alpha), g_b.view_as(b_alpha), None, None, None, None, None, None, None
 
 
@@ -181,10 +193,10 @@ class GNNLayer(nn.Module):
         return engine.layer_fwd(frontier, graph, level, nodes_new, hidden_p, rela_p, self.in_dim, a_s, a_r, a_q,
                                 self.w_alpha.weight.reshape(-1).contiguous(), self.w_alpha.bias, self.attn_dim)
 
-    def aggregate(self, q_rel, hidden, frontier, graph, level, nodes_new, nodes_old):
-        """models.py:29-39 on the device; returns message_agg [n_new, in_dim]."""
+    def aggregate(self, q_rel, hidden, lease, graph, level, nodes_new, nodes_old):
+        """models.py:29-39 on the device; returns message_agg [n_new, in_dim].  ``lease``: engine.FrontierLease of the forward."""
         d, a = self.in_dim, self.attn_dim
-        ld, ap = max(16, _pad4(d)), _pad4(a)
+        ld, ap = max(16, _pad4(d)), pad_attn(a)
         rela = self.rela_embed.weight
         pad_rows = lambda w: F.pad(w, (0, 0, 0, ap - a)) if ap != a else w
         a_s = tall_linear(hidden, pad_rows(self.Ws_attn.weight))                                # [n_old, ap]
@@ -193,11 +205,11 @@ class GNNLayer(nn.Module):
         if ld != d:
             hidden, rela = F.pad(hidden, (0, ld - d)), F.pad(rela, (0, ld - d))
         agg = _Aggregate.apply(hidden, rela, a_s, a_r, a_q, self.w_alpha.weight.reshape(-1), self.w_alpha.bias,
-                               frontier, graph, level, nodes_new, nodes_old, d, a)
+                               lease, graph, level, nodes_new, nodes_old, d, a)
         return agg[:, :d] if ld != d else agg
 
-    def forward(self, q_sub, q_rel, hidden, frontier, graph, level, nodes_new, nodes_old):
-        agg = self.aggregate(q_rel, hidden, frontier, graph, level, nodes_new, nodes_old)
+    def forward(self, q_sub, q_rel, hidden, lease, graph, level, nodes_new, nodes_old):
+        agg = self.aggregate(q_rel, hidden, lease, graph, level, nodes_new, nodes_old)
         return self.act(tall_linear(agg, self.W_h.weight))                       # models.py:41
 
 
@@ -215,7 +227,7 @@ class _GraphedInference:
     def __init__(self, model, graph, n, device, hints):
         self.model, self.graph, self.n, self.hints = model, graph, n, hints
         d, a = model.hidden_dim, model.attn_dim
-        self.ld, self.ap = max(16, _pad4(d)), _pad4(a)
+        self.ld, self.ap = max(16, _pad4(d)), pad_attn(a)
         n_ent = graph.n_ent
         cap = self.cap = n * n_ent
         f32 = dict(dtype=torch.float32, device=device)
@@ -260,8 +272,9 @@ class _GraphedInference:
             fr.expand_async(graph)
             fr.nodes_into(self.nodes, self.prev)
             a_r, a_q, rela_p = tables[i]
-            engine.layer_fwd_into(fr, graph, fr.level, self.hints[i], hidden, rela_p, d, a_s, a_r, a_q,
-                                  layer.w_alpha.weight.reshape(-1).contiguous(), layer.w_alpha.bias, a, self.agg, self.scratch)
+            n_hint, walk = self.hints[i]
+            engine.layer_fwd_into(fr, graph, fr.level, n_hint, hidden, rela_p, d, a_s, a_r, a_q,
+                                  layer.w_alpha.weight.reshape(-1).contiguous(), layer.w_alpha.bias, a, self.agg, self.scratch, walk=walk)
             last = i + 1 == m.n_layer
             out_h, out_a = self.hid[i % 2], self.a_s[i % 2]
             engine.dense_fwd_dev(self.cap, fr.count_ptr(), self.agg, hidden, self.prev, d, layer.W_h.weight, m.act_name, m.gate, out_h,
@@ -297,7 +310,7 @@ class RED_GNN_trans(nn.Module):
         self.dropout = nn.Dropout(params.dropout)
         self.W_final = nn.Linear(self.hidden_dim, 1, bias=False)
         self.gate = nn.GRU(self.hidden_dim, self.hidden_dim)     # parameters only; the single step runs as gru_cell
-        self._frontiers = {}
+        self._frontiers = engine.FrontierPool()
         self._last_stats = None
         self.fused_dense = True      # inference: W_h + GRU + projections + readout in one MFMA kernel (rg_dense_fwd)
         self.use_graphs = True       # inference: replay a captured HIP graph per (graph, batch size) from the third call on
@@ -315,13 +328,8 @@ class RED_GNN_trans(nn.Module):
         self._last_stats = value
 
     def _frontier(self, n_ent, batch, n_levels, device):
-        key = (n_ent, batch, n_levels, str(device))
-        fr = self._frontiers.get(key)
-        if fr is None:
-            if len(self._frontiers) > 8:
-                self._frontiers.clear()
-            fr = self._frontiers[key] = engine.Frontier(n_ent, batch, n_levels, device)
-        return fr
+        """A Frontier of this shape that no live autograd graph still needs (engine.FrontierPool)."""
+        return self._frontiers.get(n_ent, batch, n_levels, device)
 
     def forward(self, subs, rels, mode="train", trace=None):
         device = self.W_final.weight.device
@@ -349,6 +357,7 @@ class RED_GNN_trans(nn.Module):
         fr.reset(q_sub)
         if fused:
             return self._forward_inference(fr, graph, q_sub, q_rel, n, device, trace)
+        lease = engine.FrontierLease(fr)      # lives as long as the autograd contexts of this forward
 
         d = self.hidden_dim
         h0 = torch.zeros((n, d), device=device)                                  # models.py:72
@@ -365,7 +374,7 @@ class RED_GNN_trans(nn.Module):
             layer = self.gnn_layers[i]
             if fused_train:
                 # models.py:80-83 with the dense part in one kernel: W_h + act, h0 carry (gather by prev_idx), dropout, GRU step
-                agg = layer.aggregate(q_rel, hidden, fr, graph, fr.level, nodes, nodes_old)
+                agg = layer.aggregate(q_rel, hidden, lease, graph, fr.level, nodes, nodes_old)
                 mask = None
                 if self.training and self.dropout.p > 0.0:
                     keep = 1.0 - self.dropout.p
@@ -373,7 +382,7 @@ class RED_GNN_trans(nn.Module):
                 hidden = _DenseStep.apply(agg, h0, layer.W_h.weight, g.weight_ih_l0, g.weight_hh_l0, g.bias_ih_l0, g.bias_hh_l0,
                                           prev_idx, old_new, mask, self.act_name, g, 1.0 - self.dropout.p)
             else:
-                hidden = layer(q_sub, q_rel, hidden, fr, graph, fr.level, nodes, nodes_old)                # models.py:80
+                hidden = layer(q_sub, q_rel, hidden, lease, graph, fr.level, nodes, nodes_old)             # models.py:80
                 h0 = torch.zeros((n_new, d), device=device).index_copy(0, old_new.long(), h0)           # models.py:81
                 hidden = self.dropout(hidden)                                        # models.py:82
                 hidden = gru_step(hidden, h0, g)                                     # models.py:83
@@ -414,13 +423,13 @@ class RED_GNN_trans(nn.Module):
             g = None
             self._graphed.pop(key)
         if g is None:
-            ld, ap = max(16, _pad4(self.hidden_dim)), _pad4(self.attn_dim)
+            ld, ap = max(16, _pad4(self.hidden_dim)), pad_attn(self.attn_dim)
             seen = self._seen.get(key, 0)
             self._seen[key] = seen + 1
             if seen < 2 or _GraphedInference.bytes_needed(n, graph.n_ent, ld, ap) > _GraphedInference.MAX_BYTES:
                 self._pending_key = key          # the eager run that follows records its per-hop sizes under this key
                 return None
-            hints = self._hints.get(key) or [n * graph.n_ent] * self.n_layer
+            hints = self._hints.get(key) or [(n * graph.n_ent, 1)] * self.n_layer      # (node count, walk) per hop
             if key in self._graph_failed:
                 return None
             # a split's evaluation uses a few shapes (the batch size and the last, partial batches): keep them all, within a
@@ -446,7 +455,7 @@ class RED_GNN_trans(nn.Module):
         """The same forward with no autograd graph: per layer one expansion, one fused message-passing
         kernel and one fused dense kernel; hidden / a_s never leave their padded device layout."""
         d, a = self.hidden_dim, self.attn_dim
-        ld, ap = max(16, _pad4(d)), _pad4(a)
+        ld, ap = max(16, _pad4(d)), pad_attn(a)
         n_ent = graph.n_ent
         hidden = torch.zeros((n, ld), device=device)
         a_s = torch.zeros((n, ap), device=device)                     # hidden == 0 at layer 0 (models.py:74)
@@ -455,10 +464,10 @@ class RED_GNN_trans(nn.Module):
         nodes = None
         tables = self.inference_tables(q_rel, ld, ap)
         for i in range(self.n_layer):
-            n_new, n_e, _ = fr.expand(graph)
+            n_new, n_e, n_old = fr.expand(graph)
             nodes, prev_idx, old_new = fr.nodes(want_prev=True, want_old_new=trace is not None)
             n_edges.append(n_e)
-            sizes.append(n_new)
+            sizes.append((n_new, engine.layer_fwd_plan(fr, graph, fr.level, n_old, n_new, n_e, ld)))
             layer = self.gnn_layers[i]
             agg = layer.aggregate_nograd(tables[i], hidden, a_s, fr, graph, fr.level, nodes)
             last = i + 1 == self.n_layer

@@ -32,6 +32,56 @@ def shard_by_cost(costs, world):
     return [sorted(p) for p in parts]
 
 
+def shard_balanced(costs, world):
+    """Equal-count split balanced by cost: queries sorted by descending cost are dealt in snake order (0..W-1, W-1..0, ...),
+    so every rank gets n // world (+1 for the first n % world) queries and near-equal total cost.  Returns a list of sorted
+    index lists; ``unshard_order(parts)`` gives the permutation that restores query order after a rank-order gather."""
+    import numpy as np
+    order = np.argsort(-np.asarray(costs, dtype=np.float64), kind="stable")
+    parts = [[] for _ in range(world)]
+    for j, i in enumerate(order):
+        lap, pos = divmod(j, world)
+        parts[pos if lap % 2 == 0 else world - 1 - pos].append(int(i))
+    n = len(order)
+    base, extra = divmod(n, world)
+    # snake dealing leaves the counts equal when world divides n; otherwise move the surplus so that rank r holds base + (r < extra)
+    want = [base + (1 if r < extra else 0) for r in range(world)]
+    surplus = [i for r in range(world) for i in parts[r][want[r]:]]
+    parts = [p[:want[r]] for r, p in enumerate(parts)]
+    for r in range(world):
+        while len(parts[r]) < want[r]:
+            parts[r].append(surplus.pop())
+    return [sorted(p) for p in parts]
+
+
+def unshard_order(parts):
+    """inv such that cat([x[p] for p in parts])[inv] == x  (restores query order after gather_scores over cost-sharded ranks)."""
+    import numpy as np
+    cat = np.concatenate([np.asarray(p, dtype=np.int64) for p in parts]) if parts else np.zeros(0, np.int64)
+    inv = np.empty(len(cat), dtype=np.int64)
+    inv[cat] = np.arange(len(cat))
+    return inv
+
+
+def query_costs(base_triples, n_ent, subs, hops=2):
+    """Estimated cost of each query = number of edges its first ``hops`` expansions touch on the graph built from
+    ``base_triples`` (inverse and identity rows added, load_data.py:69-79): hop 1 = out-degree of the subject, hop 2 = sum of the
+    out-degrees of its neighbours (itself included through the identity row).  Host numpy, O(|KG|)."""
+    import numpy as np
+    t = np.asarray(base_triples, dtype=np.int64).reshape(-1, 3)
+    heads = np.concatenate([t[:, 0], t[:, 2], np.arange(n_ent)])
+    tails = np.concatenate([t[:, 2], t[:, 0], np.arange(n_ent)])
+    deg = np.bincount(heads, minlength=n_ent).astype(np.float64)
+    cost = deg.copy()
+    reach = deg
+    for _ in range(hops - 1):
+        nxt = np.zeros(n_ent)
+        np.add.at(nxt, heads, reach[tails])
+        reach = nxt
+        cost = cost + reach
+    return cost[np.asarray(subs, dtype=np.int64)]
+
+
 def gather_scores(local_scores, dist, sizes=None, async_op=False):
     """All-gather of [b_r, n_ent] score shards into [sum b_r, n_ent] on every rank (rank order).
     ``async_op=True`` returns (work, out): the collective runs on the RCCL stream and overlaps whatever the

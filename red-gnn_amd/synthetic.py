@@ -18,7 +18,7 @@ SHAPES = {
     "C2": dict(n_ent=10_000, n_rel=50, n_triples=200_000, n_layer=3, hidden_dim=64, attn_dim=5),
     "C3": dict(n_ent=40_000, n_rel=11, n_triples=93_000, n_layer=5, hidden_dim=64, attn_dim=5),
     "C4": dict(n_ent=15_000, n_rel=237, n_triples=310_000, n_layer=4, hidden_dim=128, attn_dim=5),
-    "C5": dict(n_ent=7_000, n_rel=230, n_triples=90_000, n_layer=5, hidden_dim=64, attn_dim=30),
+    "C5": dict(n_ent=7_000, n_rel=230, n_triples=90_000, n_layer=5, hidden_dim=64, attn_dim=30, n_time=365),
 }
 
 
@@ -79,6 +79,43 @@ def make_synthetic_kg(n_ent, n_rel, n_triples, seed=1234, extra_frac=0.05):
 def make_shape(name, seed=1234):
     s = SHAPES[name]
     return make_synthetic_kg(s["n_ent"], s["n_rel"], s["n_triples"], seed=seed)
+
+
+@dataclass
+class SyntheticTKG:
+    """Quadruple graph in the layout of Temporal/interpolation/graph.py:34-49: forward quads, their '~' inverses
+    (relation + n_rel_base) and one identity row per entity (relation 2*n_rel_base, sentinel time id = n_time_base)."""
+    n_ent: int
+    n_rel: int          # relation ids in the graph incl. inverses and idd (rows of the relation tables = n_rel + 1)
+    n_time: int         # time ids incl. the sentinel
+    quads: np.ndarray   # int32 [n,4] (head, rel, tail, time id), identity rows last
+    n_base: int         # number of forward quads (rows [0, n_base) of ``quads``)
+
+
+def make_temporal_kg(n_ent, n_rel_base, n_time_base, n_quads, seed=1234):
+    """ICEWS14-shaped synthetic (BASELINE configs[4]): heads/tails Zipf(1.0) over a random permutation mixed 50/50 with
+    uniform draws (as make_synthetic_kg), relations and timestamps uniform."""
+    rng = np.random.default_rng(seed)
+    perm = rng.permutation(n_ent)
+    w = _zipf_p(n_ent)
+
+    def ent(n):
+        return np.where(rng.random(n) < 0.5, perm[rng.choice(n_ent, n, p=w)], rng.integers(0, n_ent, n))
+
+    h, t = ent(n_quads), ent(n_quads)
+    r = rng.integers(0, n_rel_base, n_quads)
+    tau = rng.integers(0, n_time_base, n_quads)
+    quads = np.stack([h, r, t, tau], 1)
+    inv = np.stack([t, r + n_rel_base, h, tau], 1)
+    n_rel = 2 * n_rel_base + 1
+    idd = np.stack([np.arange(n_ent), np.full(n_ent, n_rel - 1), np.arange(n_ent), np.full(n_ent, n_time_base)], 1)
+    return SyntheticTKG(n_ent=n_ent, n_rel=n_rel, n_time=n_time_base + 1,
+                        quads=np.concatenate([quads, inv, idd], 0).astype(np.int32), n_base=n_quads)
+
+
+def make_temporal_shape(name="C5", seed=1234):
+    s = SHAPES[name]
+    return make_temporal_kg(s["n_ent"], s["n_rel"], s.get("n_time", 365), s["n_triples"], seed=seed)
 
 
 def write_task_dir(kg, task_dir):

@@ -22,7 +22,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import engine
-from .models import tall_linear
+from .models import pad_attn, tall_linear
 
 
 def _pad4(n):
@@ -33,21 +33,24 @@ class _TAggregate(torch.autograd.Function):
     """agg = rg_tlayer_fwd(...);  backward = rg_tlayer_bwd(...)."""
 
     @staticmethod
-    def forward(ctx, hidden_dir, rela_dir, time_dir, a_s, a_r, a_q, w_alpha, b_alpha, frontier, graph, level, n_new, q_time,
+    def forward(ctx, hidden_dir, rela_dir, time_dir, a_s, a_r, a_q, w_alpha, b_alpha, lease, graph, level, n_new, q_time,
                 d, attn_dim):
         hidden_dir, rela_dir, time_dir, a_s, a_r, a_q, w_alpha = (t.contiguous() for t in (hidden_dir, rela_dir, time_dir, a_s, a_r, a_q, w_alpha))
-        agg = engine.tlayer_fwd(frontier, graph, level, n_new, q_time, hidden_dir, rela_dir, time_dir, d, a_s, a_r, a_q,
+        agg = engine.tlayer_fwd(lease.frontier, graph, level, n_new, q_time, hidden_dir, rela_dir, time_dir, d, a_s, a_r, a_q,
                                 w_alpha, b_alpha, attn_dim)
         ctx.save_for_backward(hidden_dir, rela_dir, time_dir, a_s, a_r, a_q, w_alpha, b_alpha, q_time)
-        ctx.misc = (frontier, graph, level, d, attn_dim)
+        ctx.misc = (lease, graph, level, d, attn_dim)      # the lease keeps the frontier's level bitmaps for this graph's backward
         return agg
 
     @staticmethod
     def backward(ctx, grad_agg):
         hidden_dir, rela_dir, time_dir, a_s, a_r, a_q, w_alpha, b_alpha, q_time = ctx.saved_tensors
-        frontier, graph, level, d, attn_dim = ctx.misc
-        g_hd, g_rd, g_td, g_as, g_ar, g_aq, g_w = engine.tlayer_bwd(frontier, graph, level, a_s.shape[0], q_time, hidden_dir, rela_dir,
+        lease, graph, level, d, attn_dim = ctx.misc
+        lease.check()
+        g_hd, g_rd, g_td, g_as, g_ar, g_aq, g_w = engine.tlayer_bwd(lease.frontier, graph, level, a_s.shape[0], q_time, hidden_dir, rela_dir,
                                                               time_dir, d, a_s, a_r, a_q, w_alpha, b_alpha, attn_dim, grad_agg)
+        if level == 1:
+            lease.release()
         return (g_hd, g_rd, g_td, g_as, g_ar, g_aq, g_w.view_as(w_alpha)) + (None,) * 8
 
 
@@ -80,7 +83,7 @@ class T_RED_GNN(nn.Module):
         self.quads = np.ascontiguousarray(np.asarray(params.graph, dtype=np.int32).reshape(-1, 4))
         self.graph = engine.TemporalGraph(self.n_ent, self.n_rel + 1, self.n_time, self.quads,
                                           device=getattr(params, "device", "cuda"))
-        self._frontiers = {}
+        self._frontiers = engine.FrontierPool()
         self.last_stats = None
 
     def _tables(self, i):
@@ -89,13 +92,7 @@ class T_RED_GNN(nn.Module):
         return self.rela_embed_layer[i].weight, self.attention_1_layer[i].weight, self.attention_2_layer[i].weight
 
     def _frontier(self, n, n_levels, device):
-        key = (n, n_levels, str(device))
-        fr = self._frontiers.get(key)
-        if fr is None:
-            if len(self._frontiers) >= 8:
-                self._frontiers.clear()
-            fr = self._frontiers[key] = engine.Frontier(self.n_ent, n, n_levels, device)
-        return fr
+        return self._frontiers.get(self.n_ent, n, n_levels, device)
 
     def forward(self, batch, mode="train"):
         device = self.linear_classifier.weight.device
@@ -111,8 +108,9 @@ class T_RED_GNN(nn.Module):
         with_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         fr = self._frontier(n, self.n_layer + 1 if with_grad else 2, device)
         fr.reset(heads)
+        lease = engine.FrontierLease(fr) if with_grad else None
         d, a = self.hidden_dim, self.attn_dim
-        ld, ap = max(16, _pad4(d)), _pad4(a)
+        ld, ap = max(16, _pad4(d)), pad_attn(a)
         w_dir = torch.cat([self.past_linear.weight, self.now_linear.weight, self.future_linear.weight], 0)     # [3d, d]
         padc = lambda t: F.pad(t, (0, ld - d)) if ld != d else t
         pad_rows = lambda w: F.pad(w, (0, 0, 0, ap - a)) if ap != a else w
@@ -133,7 +131,7 @@ class T_RED_GNN(nn.Module):
             rela_dir = padc(F.linear(rela, w_dir).view(-1, 3, d).transpose(0, 1).reshape(-1, d)).contiguous()   # row dir*(R+1) + r
             w_alpha = w2.reshape(-1).contiguous()
             if with_grad:
-                agg = _TAggregate.apply(hidden_dir, rela_dir, time_dir, a_s, a_r, a_q, w_alpha, zero_b, fr, graph, fr.level, n_new,
+                agg = _TAggregate.apply(hidden_dir, rela_dir, time_dir, a_s, a_r, a_q, w_alpha, zero_b, lease, graph, fr.level, n_new,
                                         q_time, d, a)
             else:
                 with torch.no_grad():

@@ -125,6 +125,64 @@ def test_shard_helpers():
     assert abs(sum([9, 1, 1, 1, 8, 2, 2, 2][i] for i in parts[0]) - 13) <= 1
 
 
+def test_balanced_cost_sharding_and_costs():
+    """bench.py's split for N > 1 (per-query cost varies by far more than 2x): equal counts, every query exactly
+    once, the inverse permutation restores query order, hub subjects are spread over the ranks."""
+    from red_gnn_amd.sharding import query_costs, shard_balanced, unshard_order
+    from red_gnn_amd.synthetic import make_synthetic_kg
+    kg = make_synthetic_kg(500, 5, 4000, seed=3)
+    base = np.concatenate([kg.facts, kg.train], 0)
+    subs = kg.test[:64, 0]
+    costs = query_costs(base, kg.n_ent, subs)
+    og = orc.OracleGraph(orc.double_triple(base, kg.n_rel), kg.n_ent, kg.n_rel)
+    for i in (0, 5, 63):                                         # cost = edges of hop 1 + hop 2 of the oracle's expansion
+        nodes = np.array([[0, subs[i]]])
+        e = 0
+        for _ in range(2):
+            nodes, edges, _ = orc.get_neighbors(og, nodes)
+            e += len(edges)
+        assert costs[i] == e
+    for world in (2, 3, 8):
+        parts = shard_balanced(costs, world)
+        assert sorted(sum(parts, [])) == list(range(64))
+        assert max(map(len, parts)) - min(map(len, parts)) <= 1
+        x = np.arange(64) * 7
+        assert np.array_equal(np.concatenate([x[p] for p in parts])[unshard_order(parts)], x)
+        loads = [costs[p].sum() for p in parts]
+        contiguous = [costs[a:b].sum() for a, b in (__import__("red_gnn_amd.sharding", fromlist=["x"]).shard_slice(64, world, r) for r in range(world))]
+        assert max(loads) / min(loads) <= max(contiguous) / min(contiguous) + 1e-9
+
+
+def _gloo_cost_worker(rank, world, port, ret):
+    import torch.distributed as dist
+    from red_gnn_amd.sharding import gather_scores, query_costs, shard_balanced, unshard_order
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        fx = U.load("tiny_fwd.npz")
+        g = U.oracle_graph(fx, "test")
+        p = U.params_of(fx)
+        base = np.concatenate([fx["facts"], fx["train"]], 0)
+        parts = shard_balanced(query_costs(base, int(fx["n_ent"]), fx["subs"]), world)      # every rank computes the same split
+        mine = np.asarray(parts[rank])
+        local = orc.forward(p, g, fx["subs"][mine], fx["rels"][mine], int(fx["cfg"][0]), act=str(fx["act"]))
+        full = gather_scores(local, dist)[torch.as_tensor(unshard_order(parts))]            # rank order -> query order
+        if rank == 0:
+            ret["full"] = full.numpy()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_cost_sharded_gather_restores_query_order_gloo():
+    import torch.multiprocessing as mp
+    port = 31500 + os.getpid() % 2000
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_gloo_cost_worker, args=(2, port, ret), nprocs=2, join=True)
+        fx = U.load("tiny_fwd.npz")
+        np.testing.assert_allclose(ret["full"], fx["scores"], rtol=1e-4, atol=1e-5)
+
+
 def _gloo_worker(rank, world, port, ret):
     import torch.distributed as dist
     from red_gnn_amd.sharding import allreduce_gradients, gather_scores, reduce_metrics, shard_slice
@@ -170,6 +228,38 @@ def test_bench_byte_model():
     import bench
     assert bench.algorithmic_bytes(10, 3, 64) == 10 * 272 + 3 * 256
     assert bench.algorithmic_bytes(1, 1, 128) == 528 + 512
+
+
+def test_bench_roofline_objects():
+    """bench.layer_rooflines on round 1's measured launches (C2, B=1024: profiles/r01/final_pmc_B1024.json durations): the
+    contract's HBM object may exceed 1 (its byte model counts L2-served rows as HBM), the L2-gather object - the roof that
+    binds - must not; stored PMC traffic is only attached to the workload and kernel version it was measured on."""
+    import json
+    import bench
+    ev = [(0.43, 1.33e6, 1.29e6), (4.03, 52.0e6, 8.2e6), (7.15, 388.5e6, 10.0e6)] * 4
+    roof, l2, hops = bench.layer_rooflines(ev, 64, 3)
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["launches"] == 12 and roof["traffic"] is None
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12 and roof["frac"] > 1.0
+    assert l2["bound"] == "l2-gather" and 0.0 < l2["frac"] <= 1.0
+    assert [h["hop"] for h in hops] == [0, 1, 2] and all(0.0 < h["l2_gather_frac"] <= 1.0 for h in hops)
+    assert hops[1]["l2_gather_frac"] < 0.5 * hops[2]["l2_gather_frac"]            # the expanding hop is the one far below its roof
+    assert bench.layer_rooflines([], 64, 3) == (None, None, None)
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "t.json")
+        with open(path, "w") as f:
+            json.dump({"entries": [{"config": "C2", "batch": 1024, "rg_version": 7, "hbm_bytes_per_launch": 4.5e9, "source": "x"}]}, f)
+        assert bench.stored_traffic("C2", 1024, 7, path)["hbm_bytes_per_launch"] == 4.5e9
+        assert bench.stored_traffic("C4", 1024, 7, path) is None and bench.stored_traffic("C2", 256, 7, path) is None
+        assert bench.stored_traffic("C2", 1024, 8, path) is None and bench.stored_traffic("C2", 1024, 7, path + ".missing") is None
+        e = bench.stored_traffic("C2", 1024, 7, path)
+    roof, _, _ = bench.layer_rooflines(ev, 64, 3, e)
+    assert roof["traffic"] == 4.5e9 and 0.0 < roof["hbm_measured_frac"] < 1.0
+    # the committed file only ever answers for the library version it was measured with
+    from red_gnn_amd import _lib
+    with open(bench.TRAFFIC_FILE) as f:
+        for e in json.load(f)["entries"]:
+            assert {"config", "batch", "rg_version", "hbm_bytes_per_launch", "source"} <= set(e)
+    assert _lib.lib().rg_version() >= 2
 
 
 def test_loader_id_cache_roundtrip():
