@@ -120,6 +120,8 @@ struct rg_graph {
 //                prefix runs over the flattened [B][W] array, so rank(b,e) = prefix + popc(word below e)
 //                is the node id in the reference's (batch, entity) order.
 constexpr int RG_MAX_LEVELS = 16;
+constexpr int RG_QSTRIDE = 32;       // ints between work-queue heads
+constexpr size_t RG_QUEUE_BYTES = 8 * RG_QSTRIDE * sizeof(int32_t);
 struct rg_frontier {
   int32_t n_ent = 0, B = 0, BW = 0, W = 0, n_levels = 0;
   uint32_t* bitsT[2] = {nullptr, nullptr};
@@ -127,7 +129,10 @@ struct rg_frontier {
   uint32_t* words_tmp = nullptr;     // [B][W] batch-major words before packing
   int32_t* prefix_tmp = nullptr;     // [B][W]
   int32_t* scan_scratch = nullptr;
-  int32_t* counters = nullptr;       // device: [0]=N (int32), [1]=error flag, [2..3]=E (uint64), [4]=N of level 0, [16..23]=work queues
+  int32_t* counters = nullptr;       // device: [0]=N (int32), [1]=error flag, [2..3]=E (uint64), [4]=N of level 0, [64..]=per-level snapshots
+  int32_t* queues = nullptr;         // device: the 8 per-XCD work-queue heads of the walks, RG_QSTRIDE ints apart (one 128-B line each:
+                                     // returning atomics to ONE line serialise at ~50 per microsecond chip-wide, measured on the word-parallel
+                                     // walk, whatever the number of distinct words in it)
   int64_t* counts_pinned = nullptr;  // host pinned [4]
   int level = -1;                    // newest level (absolute, not modulo)
   int tcur = 0;                      // which bitsT holds the newest level

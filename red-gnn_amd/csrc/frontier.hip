@@ -209,7 +209,7 @@ size_t ws_layout(int32_t n_ent, int32_t B, int32_t n_levels, size_t* off /*[8]*/
   off[2] = take((size_t)B * W * 4);                          // words_tmp
   off[3] = take((size_t)B * W * 4);                          // prefix_tmp
   off[4] = take(rg::scan_scratch_elems((int64_t)B * W) * 4); // scan scratch
-  off[5] = take(1024);                                       // counters, work queues, per-level snapshots
+  off[5] = take(1024 + RG_QUEUE_BYTES);                      // counters + per-level snapshots (1 KB), then the work-queue heads
   off[6] = take((size_t)n_levels * B * W * 8);               // bm levels
   return o;
 }
@@ -244,6 +244,7 @@ int rg_frontier_create(int32_t n_ent, int32_t batch, int32_t n_levels, void* ws,
   f->prefix_tmp = (int32_t*)(base + off[3]);
   f->scan_scratch = (int32_t*)(base + off[4]);
   f->counters = (int32_t*)(base + off[5]);
+  f->queues = f->counters + 256;
   for (int l = 0; l < n_levels; ++l) f->bm[l] = (int2*)(base + off[6] + (size_t)l * batch * f->W * 8);
   if (hipHostMalloc((void**)&f->counts_pinned, 1024, hipHostMallocDefault) != hipSuccess) {
     delete f;

@@ -5,7 +5,8 @@
 
 extern "C" size_t rg_layer_fwd_scratch_bytes(const rg_frontier* f, const rg_graph* g, int32_t ld) {
   if (!f || !g) return 0;
-  return (size_t)f->B * g->in_vr.n_slots * ld * sizeof(float) + 256;
+  // partial sums of cut rows [B][n_slots][ld], then one "written" byte per partial row (word-parallel walk)
+  return rg::align_up((size_t)f->B * g->in_vr.n_slots * ld * sizeof(float), 256) + rg::align_up((size_t)f->B * g->in_vr.n_slots, 256) + 256;
 }
 
 // walk codes: 1 = per-query walk; 2, 3, 4 = word-parallel with 32, 16, 8 queries per item
@@ -59,9 +60,16 @@ extern "C" int rg_layer_fwd(const rg_frontier* f, const rg_graph* g, int32_t lev
     W.bm_old = A.bm_old; W.bm_new = A.bm_new;
     W.hidden = A.hidden; W.rela = A.rela; W.ld4 = A.ld4; W.a_s = A.a_s; W.a_r = A.a_r; W.a_q = A.a_q;
     W.w_alpha = w_alpha; W.b_alpha = b_alpha; W.attn_dim = attn_dim; W.n_rela_rows = g->n_rela_rows;
-    W.agg = A.agg; W.partial = A.partial; W.queues = f->counters + 16;
+    W.agg = A.agg; W.partial = A.partial; W.queues = f->queues;
+    // a ticket is a returning atomic: about 200 edges' worth of items each (light items: hop 0; heavy ones are taken one by one)
+    const int64_t n_e = level == f->level ? f->n_edges : -1;
+    const int64_t by_work = n_e < 0 ? 2 : 200 * W.n_items / std::max<int64_t>(n_e, 1);
+    W.ipt = (int32_t)std::max<int64_t>(std::min<int64_t>(std::min<int64_t>(by_work, W.n_items / 8192), 32), 1);   // ... and never fewer tickets than waves
+    const size_t n_part = (size_t)f->B * g->in_vr.n_slots;
+    W.written = n_part ? (uint8_t*)scratch + rg::align_up(n_part * ld * sizeof(float), 256) : nullptr;
+    if (n_part && rg::zero_async(W.written, rg::align_up(n_part, 256), s)) return 1;
     if (rgwp::launch(W, ap / 4, s)) return 1;
-    return rgfwd::launch_combine(A, f->B, g->in_vr, s);
+    return rgfwd::launch_combine(A, f->B, g->in_vr, s, W.written);
   }
   // dense walk when at least a quarter of all (query, entity) pairs are visited; else filter 64 items per wave
   // (after rg_frontier_expand_async n_new is the caller's estimate: it only picks the walk, both are exact)

@@ -203,9 +203,11 @@ __global__ __launch_bounds__(FWD_BLOCK, 6) void layer_fwd_kernel(FwdArgs A) {
   });
 }
 
-// hubs cut into segments: agg[o] = sum of the segments' partial rows, in segment order
+// hubs cut into segments: agg[o] = sum of the segments' partial rows, in segment order.  `written` (word-parallel walk only):
+// one byte per partial row, set when the segment had an edge for the query; the others were never written and count as zero.
 __global__ void combine_kernel(const int4* __restrict__ split, int n_split, int n_slots, int B, const int2* __restrict__ bm_new,
-                               int W, const float4* __restrict__ partial, float4* __restrict__ agg, int ld4) {
+                               int W, const float4* __restrict__ partial, float4* __restrict__ agg, int ld4,
+                               const uint8_t* __restrict__ written) {
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t item = tid / ld4;
   const int c = (int)(tid - item * ld4);
@@ -217,19 +219,30 @@ __global__ void combine_kernel(const int4* __restrict__ split, int n_split, int 
   if (!((word >> bit) & 1u)) return;
   const int o = wp.y + __popc(word & ((1u << bit) - 1u));
   const float4* p = partial + ((int64_t)b * n_slots + se.y) * ld4 + c;
-  float4 acc = p[0];
-  for (int k = 1; k < se.z; ++k) {
-    const float4 v = p[(int64_t)k * ld4];
-    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  float4 acc;
+  if (written) {
+    const uint8_t* wr = written + (int64_t)b * n_slots + se.y;
+    acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < se.z; ++k) {
+      if (!wr[k]) continue;
+      const float4 v = p[(int64_t)k * ld4];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  } else {
+    acc = p[0];
+    for (int k = 1; k < se.z; ++k) {
+      const float4 v = p[(int64_t)k * ld4];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
   }
   agg[(int64_t)o * ld4 + c] = acc;
 }
 
-inline int launch_combine(const FwdArgs& A, int B, const rg_vrows& vr, hipStream_t s) {
+inline int launch_combine(const FwdArgs& A, int B, const rg_vrows& vr, hipStream_t s, const uint8_t* written = nullptr) {
   if (vr.n_split > 0) {
     const int64_t threads = (int64_t)B * vr.n_split * A.ld4;
     hipLaunchKernelGGL(combine_kernel, dim3(rg::ceil_div(threads, 256)), dim3(256), 0, s, vr.split, vr.n_split, vr.n_slots, B,
-                       A.bm_new, A.W, A.partial, A.agg, A.ld4);
+                       A.bm_new, A.W, A.partial, A.agg, A.ld4, written);
     RG_LAUNCH_CHECK();
   }
   return 0;
@@ -242,7 +255,7 @@ int launch3(const FwdArgs& A, size_t lds, int B, const rg_vrows& vr, hipStream_t
   if (lds > 64 * 1024) RG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int per_cu = lds <= 53 * 1024 ? 3 : (lds <= 80 * 1024 ? 2 : 1);
   const int grid = rg::walk_grid(A.walk.n_items, BLOCK, G, DENSE, per_cu, KPG);
-  if (rg::zero_async(A.walk.queues, 8 * sizeof(int32_t), s)) return 1;
+  if (rg::zero_async(A.walk.queues, RG_QUEUE_BYTES, s)) return 1;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds, s, A);
   RG_LAUNCH_CHECK();
   return launch_combine(A, B, vr, s);
@@ -305,7 +318,7 @@ inline int fill_common(const char* who, const rg_frontier* f, const rg_graph* g,
   const int64_t n_items = (int64_t)f->B * g->in_vr.n;
   RG_CHECK(n_items / 8 + ((int64_t)1 << 26) < ((int64_t)1 << 31), "%s: work space too large for 32-bit queue tickets", who);
   A->walk.n_items = n_items; A->walk.n_vrows = g->in_vr.n; A->walk.n_slots = g->in_vr.n_slots; A->walk.vrows = g->in_vr.rows;
-  A->walk.bm_test = f->bm_of(level); A->walk.W = f->W; A->walk.queues = f->counters + 16;
+  A->walk.bm_test = f->bm_of(level); A->walk.W = f->W; A->walk.queues = f->queues;
   A->in_hr = g->in_hr; A->in_pk = g->in_pk;
   A->bm_old = f->bm_of(level - 1); A->bm_new = f->bm_of(level); A->W = f->W;
   A->ld4 = ld / 4; A->attn_dim = attn_dim; A->n_rela_rows = g->n_rela_rows; A->rela_in_lds = 0;

@@ -27,7 +27,9 @@ struct WpArgs {
   int attn_dim, n_rela_rows;
   float4* agg;
   float4* partial;
-  int32_t* queues;            // [8], zeroed by the launcher
+  uint8_t* written;           // [B * n_slots]: set where a partial sum was stored (zeroed by the caller)
+  int32_t* queues;            // 8 heads, RG_QSTRIDE ints apart, zeroed by the launcher
+  int32_t ipt;                // items per queue ticket
 };
 
 // launches the kernel (and nothing else: the caller runs combine_kernel for cut rows, as after the per-query walk)

@@ -23,7 +23,7 @@ struct WalkArgs {
   const int4* vrows;
   const int2* bm_test;
   int W;
-  int32_t* queues;   // [8] item offsets inside each eighth, zeroed before the launch
+  int32_t* queues;   // 8 heads, RG_QSTRIDE ints apart: item offsets inside each eighth, zeroed before the launch
 };
 
 // DENSE walks take KPG items per lane group and block step: 1 for graphs of long rows (C2: 34 entries per row),
@@ -73,17 +73,17 @@ __device__ __forceinline__ void walk_items(const WalkArgs& A, int4* recs, F&& ru
       }
       q = (q + 1) & 7;
       if (++n_dry == 8) { out[2] = 0; return; }
-      off = atomicAdd(&A.queues[q], STEP);
+      off = atomicAdd(&A.queues[q * RG_QSTRIDE], STEP);
     }
   };
-  if (threadIdx.x == 0) resolve(atomicAdd(&A.queues[q], STEP), slot[0]);
+  if (threadIdx.x == 0) resolve(atomicAdd(&A.queues[q * RG_QSTRIDE], STEP), slot[0]);
   int4* my_recs = recs + wv * 64;
   for (int p = 0;; p ^= 1) {
     __syncthreads();
     const int b0 = slot[p][0], vr0 = slot[p][1], cnt_items = slot[p][2];
     if (cnt_items == 0) break;
     int next_off = 0;
-    if (threadIdx.x == 0) next_off = atomicAdd(&A.queues[q], STEP);     // prefetch the next ticket
+    if (threadIdx.x == 0) next_off = atomicAdd(&A.queues[q * RG_QSTRIDE], STEP);     // prefetch the next ticket
 
     if constexpr (DENSE) {
 #pragma unroll 1
