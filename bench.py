@@ -268,6 +268,7 @@ def main():
     q_idx = glob[mine]
     subs, rels, a_ptr, a_idx, f_ptr, f_idx = loader.get_batch_csr(q_idx, data="test")
 
+    engine.FORCE_WALK = int(os.environ.get("RG_BENCH_FORCE_WALK", "0"))      # (kernel experiments: tools/pmc.sh runs with a forced walk)
     kernel_events, dense_events = [], []
     if not args.no_kernel_events and not args.graphs:
         engine.KERNEL_EVENTS = kernel_events

@@ -11,12 +11,16 @@ extern "C" size_t rg_layer_fwd_scratch_bytes(const rg_frontier* f, const rg_grap
 
 // walk codes: 1 = per-query walk; 2, 3, 4 = word-parallel with 32, 16, 8 queries per item
 static int plan_walk(const rg_frontier* f, const rg_graph* g, int32_t level, int64_t n_old, int64_t n_new, int64_t n_edges, int32_t ld) {
-  if (g->in_pk_packs.n == 0 || level != f->level || n_old < 0 || n_new <= 0 || n_edges < 0) return 1;
+  if (g->in_pk_packs.n == 0 || level != f->level || n_old < 0 || n_new <= 0 || n_edges < 0 || !rgwp::offsets_fit(n_old, ld)) return 1;
   // per-query walk: tests every in-edge of every live destination (~ n_new * mean in-degree candidates) after testing all
   // B * n_vrows items; word-parallel: touches the valid edges only, 32 queries' source rows per XCD at a time
   const double candidates = (double)n_new * (double)g->n_fact / (double)g->n_ent;
   const bool tiny = n_new * 16 < (int64_t)f->B * f->n_ent;
-  if (!tiny && (double)n_edges >= 0.4 * candidates) return 1;
+  // graphs of short rows (WN18RR-like: 5 in-edges per entity): the per-query walk pays its per-destination work (bitmap test,
+  // ranks, lane-group set-up) for a handful of edges, the word-parallel walk packs rows into full waves: measured on C3 (B = 256)
+  // it is 1.2-1.6x faster on every hop, saturated ones included (on C2 / C4, 41 in-edges per entity, 2x slower there)
+  const bool short_rows = (double)g->n_fact < 12.0 * (double)g->n_ent;
+  if (!tiny && !short_rows && (double)n_edges >= 0.4 * candidates) return 1;
   const double group_bytes = (double)n_old * ld * sizeof(float) / f->BW;      // source rows of one bitmap word's queries
   return group_bytes <= 3.0 * (1 << 20) ? 2 : (group_bytes <= 6.0 * (1 << 20) ? 3 : 4);
 }
@@ -34,7 +38,9 @@ extern "C" int rg_layer_fwd(const rg_frontier* f, const rg_graph* g, int32_t lev
   RG_CHECK(f && g && hidden && rela && a_s && a_r && a_q && w_alpha && b_alpha && agg_out, "rg_layer_fwd: NULL argument");
   RG_CHECK((((uintptr_t)hidden | (uintptr_t)rela | (uintptr_t)a_s | (uintptr_t)a_r | (uintptr_t)a_q | (uintptr_t)agg_out |
              (uintptr_t)scratch) & 15) == 0, "rg_layer_fwd: float buffers must be 16-B aligned");
-  RG_CHECK(walk >= 0 && walk <= 4, "rg_layer_fwd: walk=%d not in 0..4", walk);
+  const int variant = walk >> 4;      // (tuning aid: bits 4-5 pick a lane grouping of the word-parallel kernel; 0 = default)
+  walk &= 15;
+  RG_CHECK(walk >= 0 && walk <= 4 && variant <= 2, "rg_layer_fwd: walk=%d not in 0..4", walk);
   rgfwd::FwdArgs A;
   if (rgfwd::fill_common("rg_layer_fwd", f, g, level, n_new, d, ld, ap, attn_dim, scratch, scratch_bytes,
                          rg_layer_fwd_scratch_bytes(f, g, ld), &A)) return 1;
@@ -51,6 +57,10 @@ extern "C" int rg_layer_fwd(const rg_frontier* f, const rg_graph* g, int32_t lev
     RG_CHECK(g->in_pk_packs.n > 0, "rg_layer_fwd: the word-parallel walk needs a static graph with packed entries");
     RG_CHECK(level == f->level, "rg_layer_fwd: the word-parallel walk reads the entity-major bitmaps of the newest hop only "
              "(level %d, newest %d)", level, f->level);
+    // (after rg_frontier_expand_async the previous level's size is not known here: bounded by the full grid)
+    const int64_t n_old = f->n_nodes[(level - 1) % f->n_levels] >= 0 ? f->n_nodes[(level - 1) % f->n_levels] : (int64_t)f->B * f->n_ent;
+    RG_CHECK(rgwp::offsets_fit(n_old, ld), "rg_layer_fwd: the word-parallel walk addresses the previous level by 32-bit byte offsets "
+             "(%lld rows x %d floats is 4 GiB or more)", (long long)n_old, ld);
     rgwp::WpArgs W;
     W.n_sub = 1 << (walk - 2);
     W.n_packs = g->in_pk_packs.n; W.BW = f->BW; W.W = f->W; W.n_slots = g->in_vr.n_slots;
@@ -68,7 +78,7 @@ extern "C" int rg_layer_fwd(const rg_frontier* f, const rg_graph* g, int32_t lev
     const size_t n_part = (size_t)f->B * g->in_vr.n_slots;
     W.written = n_part ? (uint8_t*)scratch + rg::align_up(n_part * ld * sizeof(float), 256) : nullptr;
     if (n_part && rg::zero_async(W.written, rg::align_up(n_part, 256), s)) return 1;
-    if (rgwp::launch(W, ap / 4, s)) return 1;
+    if (rgwp::launch(W, ap / 4, variant, s)) return 1;
     return rgfwd::launch_combine(A, f->B, g->in_vr, s, W.written);
   }
   // dense walk when at least a quarter of all (query, entity) pairs are visited; else filter 64 items per wave

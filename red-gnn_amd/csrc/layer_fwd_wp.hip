@@ -14,8 +14,8 @@
 //              append {entry, b | row} to the wave's LDS queue (8 B each)
 //   phase 1  lane per queued edge: source node id (popcount rank in the previous level), attention scalar, and the edge's
 //            output row (rank of (b, t) in the new level, or the partial-sum slot of a cut row) -> 16-B tuples
-//   phase 2  the lane groups split the queue at destination boundaries and stream through their shares, four row gathers in
-//            flight: acc += alpha (hidden[s] + rela[r]); a change of output row stores the finished sum
+//   phase 2  the lane groups split the queue at destination boundaries and stream through their shares, the next edge's row
+//            in flight: acc += alpha (hidden[s] + rela[r]); a change of output row stores the finished sum
 //
 // A destination row cut into segments (hubs, > 128 in-edges) stores partial sums, flagged in `written`; combine_kernel
 // (layer_fwd_kernel.h) adds up the flagged ones in segment order (a segment with no edge for a query stores nothing).
@@ -40,14 +40,21 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
 }
 
-template <int G, int AP4, bool RELA_LDS>
+// G lanes own a row, F float4 each (lane l holds columns l, l + G, ... in float4 units: a load instruction of the group
+// covers G * 16 contiguous bytes); 64 / G destination runs are in flight per wave.  Every per-edge control and address
+// instruction is shared by the 64 / G groups, so few lanes per row = few instructions per edge (d = 64: G = 4, F = 4: 16 edges
+// per wave-instruction; the first version, 16 lanes x 1 float4 and one destination run per group at a time, spent 9.3 VALU
+// instructions per edge against 4.4 in the per-query walk and was VALU-bound at 58 % busy).
+// EXACT: the row is exactly G * F float4 wide (d = 64, 128): column offsets are instruction immediates.
+template <int G, int F, int AP4, bool RELA_LDS, bool EXACT>
 __global__ __launch_bounds__(WP_BLOCK, 4) void layer_fwd_wp_kernel(WpArgs A) {
   extern __shared__ float4 lds[];
-  constexpr int GW = 64 / G;
+  constexpr int GW = 64 / G, RW = G * F + 1;      // groups per wave; float4 per staged relation row (+1: rows of different groups
+                                                  // start in different LDS banks)
   char* wave_lds = reinterpret_cast<char*>(lds);                                 // [WAVES][WAVE_LDS]
   float4* ar_l = reinterpret_cast<float4*>(wave_lds + WP_WAVES * WAVE_LDS);      // [n_rela_rows][AP4]
   float4* w_l = ar_l + A.n_rela_rows * AP4;                                      // [AP4]
-  float4* rela_l = w_l + AP4;                                                    // [n_rela_rows][G] (optional)
+  float4* rela_l = w_l + AP4;                                                    // [n_rela_rows][RW] (optional)
 
   for (int i = threadIdx.x; i < A.n_rela_rows * AP4; i += WP_BLOCK) ar_l[i] = A.a_r[i];
   if (threadIdx.x < AP4) {
@@ -59,8 +66,8 @@ __global__ __launch_bounds__(WP_BLOCK, 4) void layer_fwd_wp_kernel(WpArgs A) {
     w_l[threadIdx.x] = make_float4(w[0], w[1], w[2], w[3]);
   }
   if constexpr (RELA_LDS) {
-    for (int i = threadIdx.x; i < A.n_rela_rows * G; i += WP_BLOCK) {
-      const int r = i / G, c = i - r * G;
+    for (int i = threadIdx.x; i < A.n_rela_rows * RW; i += WP_BLOCK) {
+      const int r = i / RW, c = i - r * RW;
       rela_l[i] = c < A.ld4 ? A.rela[(int64_t)r * A.ld4 + c] : f4zero();
     }
   }
@@ -69,22 +76,56 @@ __global__ __launch_bounds__(WP_BLOCK, 4) void layer_fwd_wp_kernel(WpArgs A) {
 
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int lane_g = lane & (G - 1), gi_w = lane / G;
-  const bool row_lane = lane_g < A.ld4;
-  const int lane_c = row_lane ? lane_g : A.ld4 - 1;      // loads never branch: idle lanes re-read the last float4
   const unsigned long long lt = (1ull << lane) - 1ull;
-  float4* st = reinterpret_cast<float4*>(wave_lds + wv * WAVE_LDS);            // tuples {s, r, alpha, output row}
+  float4* st = reinterpret_cast<float4*>(wave_lds + wv * WAVE_LDS);            // tuples {hidden row offset, relation row offset, alpha, output row}
   int2* q8 = reinterpret_cast<int2*>(st) + QCAP;                               // fill queue {packed entry, b << 8 | row}: upper half of
                                                                                // the tuples' bytes; tuple i is written after entry i is read
   unsigned long long* hmask = reinterpret_cast<unsigned long long*>(st + QCAP);   // run heads of the queue, 64 entries per word
   const int qbits = 32 / A.n_sub;
+  const uint32_t row_bytes = (uint32_t)A.ld4 * 16u;
+  // this lane's F columns (float4 units): lane_g, lane_g + G, ...; columns beyond the row re-read its last float4 (loads never
+  // branch) and are not stored.  col_d[f] = byte distance of column f from the lane's first column.
+  const uint32_t lane_off = (uint32_t)lane_g * 16u;
+  uint32_t col_d[F];
+  bool col_ok[F];
+#pragma unroll
+  for (int f = 0; f < F; ++f) {
+    const int c = lane_g + G * f;
+    col_ok[f] = EXACT || c < A.ld4;
+    col_d[f] = EXACT ? (uint32_t)(f * G * 16) : (uint32_t)((col_ok[f] ? c : A.ld4 - 1) - lane_g) * 16u;
+  }
+  const char* hidden_b = reinterpret_cast<const char*>(A.hidden);
+  const char* rela_b = reinterpret_cast<const char*>(A.rela);
+  const char* rela_lb = reinterpret_cast<const char*>(rela_l) + lane_g * 16;
 
-  auto store_row = [&](int out, const float4& acc) {
-    if (!row_lane) return;
-    if (out >= 0) {
-      A.agg[(int64_t)out * A.ld4 + lane_g] = acc;
-    } else {
-      A.partial[(int64_t)(-out - 1) * A.ld4 + lane_g] = acc;
-      if (lane_g == 0) A.written[-out - 1] = 1;
+  auto store_row = [&](int out, const float4 (&acc)[F]) {
+    float4* row = out >= 0 ? A.agg + (int64_t)out * A.ld4 : A.partial + (int64_t)(-out - 1) * A.ld4;
+#pragma unroll
+    for (int f = 0; f < F; ++f)
+      if (col_ok[f]) row[lane_g + G * f] = acc[f];
+    if (out < 0 && lane_g == 0) A.written[-out - 1] = 1;
+  };
+  auto gather = [&](const float4& t, float4 (&hv)[F]) {
+    const uint32_t off = (uint32_t)__float_as_int(t.x) + lane_off;      // 32-bit: uniform base + lane offset + immediate
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+      if constexpr (EXACT) hv[f] = *reinterpret_cast<const float4*>(hidden_b + off + f * (G * 16));     // (added in 64 bits: folds)
+      else hv[f] = *reinterpret_cast<const float4*>(hidden_b + (off + col_d[f]));
+    }
+  };
+  auto consume = [&](const float4& t, const float4 (&hv)[F], float4 (&acc)[F]) {
+    const float al = t.z;
+    const uint32_t ro = (uint32_t)__float_as_int(t.y);
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+      float4 rv;
+      if constexpr (RELA_LDS) rv = *reinterpret_cast<const float4*>(rela_lb + ro + f * (G * 16));
+      else if constexpr (EXACT) rv = *reinterpret_cast<const float4*>(rela_b + (ro + lane_off) + f * (G * 16));
+      else rv = *reinterpret_cast<const float4*>(rela_b + (ro + lane_off + col_d[f]));
+      acc[f].x = fmaf(al, hv[f].x + rv.x, acc[f].x);
+      acc[f].y = fmaf(al, hv[f].y + rv.y, acc[f].y);
+      acc[f].z = fmaf(al, hv[f].z + rv.z, acc[f].z);
+      acc[f].w = fmaf(al, hv[f].w + rv.w, acc[f].w);
     }
   };
 
@@ -97,7 +138,7 @@ __global__ __launch_bounds__(WP_BLOCK, 4) void layer_fwd_wp_kernel(WpArgs A) {
     uint32_t w0 = 0, w1 = 0;
     if (e0.x != -1) w0 = A.bits_old[(int64_t)(e0.x & 0xFFFFF) * A.BW + bw] & qmask;
     if (e1.x != -1) w1 = A.bits_old[(int64_t)(e1.x & 0xFFFFF) * A.BW + bw] & qmask;
-    const int4 P = A.pack[pi];
+    const int row0 = A.pack[pi].x;
     uint32_t todo = wave_or(w0 | w1);
     while (todo) {
       // ---- fill: the valid edges of query after query, in (query, CSR order) --------------------------------------------
@@ -141,7 +182,7 @@ __global__ __launch_bounds__(WP_BLOCK, 4) void layer_fwd_wp_kernel(WpArgs A) {
           if (valid[j]) {
             const int hd = en[j].x & 0xFFFFF, bq = bw * 32 + (en[j].y >> 8);
             const int2 wp = A.bm_old[(int64_t)bq * A.W + (hd >> 5)];
-            const int2 dst = A.rows[P.x + (en[j].y & 255)];                   // {entity, slot of a cut row's partial sum or -1}
+            const int2 dst = A.rows[row0 + (en[j].y & 255)];                  // {entity, slot of a cut row's partial sum or -1}
             s[j] = wp.y + __popc((uint32_t)wp.x & ((1u << (hd & 31)) - 1u));
             if (dst.y < 0) {
               const int2 wn = A.bm_new[(int64_t)bq * A.W + (dst.x >> 5)];
@@ -169,13 +210,16 @@ __global__ __launch_bounds__(WP_BLOCK, 4) void layer_fwd_wp_kernel(WpArgs A) {
               z = fmaf(w.w, fmaxf(as.w + ar.w + q.w, 0.f), z);
             }
             const float alpha = __builtin_amdgcn_rcpf(1.0f + __expf(-z));
-            st[i0 + j * 64 + lane] = make_float4(__int_as_float(s[j]), __int_as_float(r), alpha, __int_as_float(out[j]));
+            const uint32_t hoff = (uint32_t)s[j] * row_bytes;                 // < 2^32: checked by the launcher
+            const uint32_t roff = (uint32_t)r * (RELA_LDS ? (uint32_t)(RW * 16) : row_bytes);
+            st[i0 + j * 64 + lane] = make_float4(__int_as_float((int)hoff), __int_as_float((int)roff), alpha, __int_as_float(out[j]));
           }
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_wave_barrier();
-      // ---- phase 2: the lane groups take contiguous shares of the queue, cut at destination boundaries ------------------
+      // ---- phase 2: the lane groups take contiguous shares of the queue, cut at destination boundaries, and stream through
+      // them one edge per trip with the next edge's row already in flight ---------------------------------------------------
       auto next_head = [&](int c) -> int {       // first run head at or after queue position c (qn if none)
         int pos = qn;
 #pragma unroll
@@ -193,37 +237,36 @@ __global__ __launch_bounds__(WP_BLOCK, 4) void layer_fwd_wp_kernel(WpArgs A) {
         end = gi_w == GW - 1 ? qn : next_head((gi_w + 1) * qn / GW);
       }
       if (e < end) {
-        int cur = __float_as_int(st[e].w);
-        float4 acc = f4zero();
-        for (; e < end; e += 4) {
-          float4 tp[4], hv[4];
+        float4 acc[F], hvA[F], hvB[F];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            tp[u] = st[min(e + u, end - 1)];
-            if (e + u >= end) tp[u].z = 0.f;          // pad: the last edge again with weight 0 (same output row)
+        for (int f = 0; f < F; ++f) acc[f] = f4zero();
+        float4 tA = st[e], tB;
+        int cur = __float_as_int(tA.w);
+        gather(tA, hvA);
+        for (;;) {
+          // A is current; B = the next edge of the share (or A again past its end: loaded, never used)
+          tB = st[min(e + 1, end - 1)];
+          gather(tB, hvB);
+          consume(tA, hvA, acc);
+          if (e + 1 >= end || __float_as_int(tB.w) != cur) {
+            store_row(cur, acc);
+#pragma unroll
+            for (int f = 0; f < F; ++f) acc[f] = f4zero();
+            cur = __float_as_int(tB.w);
           }
+          if (e + 1 >= end) break;
+          tA = st[min(e + 2, end - 1)];
+          gather(tA, hvA);
+          consume(tB, hvB, acc);
+          if (e + 2 >= end || __float_as_int(tA.w) != cur) {
+            store_row(cur, acc);
 #pragma unroll
-          for (int u = 0; u < 4; ++u) hv[u] = A.hidden[(int64_t)__float_as_int(tp[u].x) * A.ld4 + lane_c];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int out = __float_as_int(tp[u].w);
-            if (out != cur) {
-              store_row(cur, acc);
-              acc = f4zero();
-              cur = out;
-            }
-            const int ru = __float_as_int(tp[u].y);
-            float4 rv;
-            if constexpr (RELA_LDS) rv = rela_l[ru * G + lane_g];
-            else rv = A.rela[(int64_t)ru * A.ld4 + lane_c];
-            const float al = tp[u].z;
-            acc.x = fmaf(al, hv[u].x + rv.x, acc.x);
-            acc.y = fmaf(al, hv[u].y + rv.y, acc.y);
-            acc.z = fmaf(al, hv[u].z + rv.z, acc.z);
-            acc.w = fmaf(al, hv[u].w + rv.w, acc.w);
+            for (int f = 0; f < F; ++f) acc[f] = f4zero();
+            cur = __float_as_int(tA.w);
           }
+          if (e + 2 >= end) break;
+          e += 2;
         }
-        store_row(cur, acc);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the queue is read out before the next fill overwrites it
       __builtin_amdgcn_wave_barrier();
@@ -263,9 +306,9 @@ __global__ __launch_bounds__(WP_BLOCK, 4) void layer_fwd_wp_kernel(WpArgs A) {
   }
 }
 
-template <int G, int AP4, bool RELA_LDS>
-int launch3(const WpArgs& A, size_t lds, hipStream_t s) {
-  auto kern = layer_fwd_wp_kernel<G, AP4, RELA_LDS>;
+template <int G, int F, int AP4, bool RELA_LDS, bool EXACT>
+int launch4(const WpArgs& A, size_t lds, hipStream_t s) {
+  auto kern = layer_fwd_wp_kernel<G, F, AP4, RELA_LDS, EXACT>;
   if (lds > 64 * 1024) RG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int per_cu = lds <= 80 * 1024 ? 2 : 1;
   const int grid = (int)std::max<int64_t>(std::min<int64_t>(rg::ceil_div(A.n_items, WP_WAVES * A.ipt), 256 * per_cu), 1);
@@ -275,36 +318,54 @@ int launch3(const WpArgs& A, size_t lds, hipStream_t s) {
   return 0;
 }
 
-template <int G, int AP4>
-int launch2(const WpArgs& A, hipStream_t s) {
-  const size_t lds = (size_t)WP_WAVES * WAVE_LDS + (size_t)(A.n_rela_rows * AP4 + AP4) * sizeof(float4);
-  const size_t rela_bytes = (size_t)A.n_rela_rows * G * sizeof(float4);
-  RG_CHECK(lds <= 160 * 1024, "rg_layer_fwd: attention tables need %zu B of LDS (> 160 KiB)", lds);
-  if (lds + rela_bytes <= 80 * 1024) return launch3<G, AP4, true>(A, lds + rela_bytes, s);    // still two workgroups per CU
-  return launch3<G, AP4, false>(A, lds, s);
+template <int G, int F, int AP4, bool RELA_LDS>
+int launch3(const WpArgs& A, size_t lds, hipStream_t s) {
+  if constexpr (G * F >= 16) {      // d = 64, 128, 256: the common widths get the immediate-offset form
+    if (A.ld4 == G * F) return launch4<G, F, AP4, RELA_LDS, true>(A, lds, s);
+  }
+  return launch4<G, F, AP4, RELA_LDS, false>(A, lds, s);
 }
 
-template <int G>
+template <int G, int F, int AP4>
+int launch2(const WpArgs& A, hipStream_t s) {
+  const size_t lds = (size_t)WP_WAVES * WAVE_LDS + (size_t)(A.n_rela_rows * AP4 + AP4) * sizeof(float4);
+  const size_t rela_bytes = (size_t)A.n_rela_rows * (G * F + 1) * sizeof(float4);
+  RG_CHECK(lds <= 160 * 1024, "rg_layer_fwd: attention tables need %zu B of LDS (> 160 KiB)", lds);
+  if (lds + rela_bytes <= 80 * 1024) return launch3<G, F, AP4, true>(A, lds + rela_bytes, s);    // still two workgroups per CU
+  return launch3<G, F, AP4, false>(A, lds, s);
+}
+
+template <int G, int F>
 int launch_ap(const WpArgs& A, int ap4, hipStream_t s) {
   switch (ap4) {
-    case 1: return launch2<G, 1>(A, s);
-    case 2: return launch2<G, 2>(A, s);
-    case 3: return launch2<G, 3>(A, s);
-    case 4: return launch2<G, 4>(A, s);
-    case 8: return launch2<G, 8>(A, s);
+    case 1: return launch2<G, F, 1>(A, s);
+    case 2: return launch2<G, F, 2>(A, s);
+    case 3: return launch2<G, F, 3>(A, s);
+    case 4: return launch2<G, F, 4>(A, s);
+    case 8: return launch2<G, F, 8>(A, s);
     default: rg::set_error("rg_layer_fwd: padded attention dim %d not in {4,8,12,16,32}", ap4 * 4); return 1;
   }
 }
 
 }  // namespace
 
-int launch(const WpArgs& A, int ap4, hipStream_t s) {
+bool offsets_fit(int64_t n_old, int32_t ld) { return n_old >= 0 && (uint64_t)n_old * ld * sizeof(float) < ((uint64_t)1 << 32); }
+
+int launch(const WpArgs& A, int ap4, int variant, hipStream_t s) {
   RG_CHECK(A.n_items / 8 + ((int64_t)1 << 26) < ((int64_t)1 << 31), "rg_layer_fwd: work space too large for 32-bit queue tickets");
-  if (A.ld4 <= 4) return launch_ap<4>(A, ap4, s);
-  if (A.ld4 <= 8) return launch_ap<8>(A, ap4, s);
-  if (A.ld4 <= 16) return launch_ap<16>(A, ap4, s);
-  if (A.ld4 <= 32) return launch_ap<32>(A, ap4, s);
-  return launch_ap<64>(A, ap4, s);
+  if (A.ld4 <= 4) return launch_ap<2, 2>(A, ap4, s);
+  if (A.ld4 <= 8) return launch_ap<4, 2>(A, ap4, s);
+  if (A.ld4 <= 16) {
+    if (variant == 1) return launch_ap<4, 4>(A, ap4, s);
+    if (variant == 2) return launch_ap<16, 1>(A, ap4, s);
+    return launch_ap<8, 2>(A, ap4, s);
+  }
+  if (A.ld4 <= 32) {
+    if (variant == 1) return launch_ap<8, 4>(A, ap4, s);
+    if (variant == 2) return launch_ap<32, 1>(A, ap4, s);
+    return launch_ap<16, 2>(A, ap4, s);
+  }
+  return launch_ap<32, 2>(A, ap4, s);
 }
 
 }  // namespace rgwp
