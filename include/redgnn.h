@@ -84,6 +84,10 @@ int rg_frontier_expand(rg_frontier* f, const rg_graph* g, int64_t* counts_host, 
  * rg_frontier_level_counts reads N and E of levels 0..current back: counts_host[2*l] = N_l, [2*l+1] = E_l
  * (room for 2 * 16 values; synchronises `stream`). */
 int rg_frontier_expand_async(rg_frontier* f, const rg_graph* g, void* stream);
+/* rg_frontier_expand_async + rg_frontier_nodes (nodes_out [batch*n_ent, 2], prev_idx_out [batch*n_ent]; either may be NULL) in one
+ * call: for small batches (batch * ceil(n_ent/32) <= 12288 words) the level build and the node list are ONE single-workgroup launch
+ * instead of six, which is what a replayed graph at the reference's n_tbatch = 50 is made of (launch latency, not work). */
+int rg_frontier_expand_nodes_async(rg_frontier* f, const rg_graph* g, int32_t* nodes_out, int32_t* prev_idx_out, void* stream);
 const int32_t* rg_frontier_count_ptr(const rg_frontier* f);
 int rg_frontier_level_counts(const rg_frontier* f, int64_t* counts_host, void* stream);
 /* nodes of the current level: nodes_out int32 [N_new,2] = (batch, entity) sorted
@@ -130,6 +134,15 @@ int rg_layer_fwd(const rg_frontier* f, const rg_graph* g, int32_t level, int64_t
                  const float* a_s, const float* a_r, const float* a_q, int32_t ap,
                  const float* w_alpha, const float* b_alpha, int32_t attn_dim,
                  float* agg_out, void* scratch_dev, size_t scratch_bytes, int32_t walk, void* stream);
+
+/* ---- hoisted attention tables of ALL layers in one launch: models.py:33,36 (Wr_attn, Wqr_attn applied per relation / per query
+ * instead of per edge).  For layer l: a_r_out[l][r][ap] = rela[l][r] . Wr[l][j], a_q_out[l][b][ap] = rela[l][q_rel[b]] . Wqr[l][j] + bqr[l][j]
+ * (columns j >= attn_dim zero), rela_pad_out[l][r][ld] = rela[l][r] zero-padded to ld columns (NULL when ld == d).
+ * rela / Wr / Wqr / bqr: HOST arrays of n_layer device pointers (tables [n_rela_rows, d], weights [attn_dim, d], bias [attn_dim]);
+ * q_rel device int64 [batch].  n_layer <= 16. */
+int rg_attn_tables(int32_t n_layer, int32_t n_rela_rows, int32_t batch, int32_t d, int32_t ld, int32_t attn_dim, int32_t ap,
+                   const float* const* rela, const float* const* Wr, const float* const* Wqr, const float* const* bqr,
+                   const int64_t* q_rel, float* a_r_out, float* a_q_out, float* rela_pad_out, void* stream);
 
 /* ---- temporal layer forward: replaces Temporal/interpolation/model_cuda.py:149-160,192 ------------------
  * agg[o] = sum_e alpha_e * (hidden_dir[3 s + dir_e] + rela_dir[dir_e * n_rela_rows + r] + time_dir[dir_e * n_time + |dt_e|]),

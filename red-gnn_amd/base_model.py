@@ -115,15 +115,37 @@ class BaseModel(object):
             p.data.nan_to_num_(nan=np.random.random(), posinf=float("inf"), neginf=float("-inf"))
 
     # ---- filtered evaluation (base_model.py:85-152) ---------------------------------------------------------------
+    EVAL_LANES = 8      # evaluation batches in flight on separate HIP streams (measured on family, n_tbatch = 50: 1 lane 119 k, 2-4 lanes 172 k, 8 lanes 263 k queries/s)
+
     def _rank_split(self, data, n_data):
+        """Filtered ranks of a split.  A 50-query batch (the reference's n_tbatch) is a chain of small dependent kernels that
+        leaves most of the 256 CUs idle, so consecutive batches go to EVAL_LANES streams round-robin: each lane replays its own
+        captured forward graph (own buffers) and ranks on its stream; the lanes run concurrently on the device."""
         mode = self.loader.eval_mode(data) if hasattr(self.loader, "eval_mode") else data
+        device = next(self.model.parameters()).device
+        batches = _chunks(n_data, self.n_tbatch)[self.rank::self.world]             # evaluation batches dealt round-robin
+        n_lanes = max(1, min(self.EVAL_LANES, len(batches)))
+        main = torch.cuda.current_stream(device)
+        if n_lanes > 1:
+            lanes = self.__dict__.setdefault("_eval_streams", [])
+            while len(lanes) < n_lanes:
+                lanes.append(torch.cuda.Stream(device=device))
+            for s in lanes[:n_lanes]:
+                s.wait_stream(main)
         ranks = []
         with torch.no_grad():
-            for idx in _chunks(n_data, self.n_tbatch)[self.rank::self.world]:       # evaluation batches dealt round-robin
-                subs, rels, ans_ptr, ans_idx, filt_ptr, filt_idx = self.loader.get_batch_csr(idx, data=data, device_queries=True)
-                scores = self.model(subs, rels, mode=mode)
-                ranks.append(cal_ranks_csr(scores, ans_ptr, ans_idx, filt_ptr, filt_idx))
-        device = next(self.model.parameters()).device
+            for i, idx in enumerate(batches):
+                stream = main if n_lanes == 1 else lanes[i % n_lanes]
+                with torch.cuda.stream(stream):
+                    subs, rels, ans_ptr, ans_idx, filt_ptr, filt_idx = self.loader.get_batch_csr(idx, data=data, device_queries=True)
+                    scores = self.model(subs, rels, mode=mode)
+                    r = cal_ranks_csr(scores, ans_ptr, ans_idx, filt_ptr, filt_idx)
+                    if stream is not main:
+                        r.record_stream(main)
+                    ranks.append(r)
+        if n_lanes > 1:
+            for s in lanes[:n_lanes]:
+                main.wait_stream(s)
         return torch.cat(ranks).double() if ranks else torch.zeros(0, dtype=torch.float64, device=device)
 
     def _performance(self, ranks):

@@ -36,6 +36,7 @@ void set_error(const char* fmt, ...);
 // launches left stale bitmap words and wrote address-like garbage into the 1 KB counter block; tools/probe_graph.py), so
 // every fill that can end up in a graph goes through these.  p 4-byte aligned, bytes a multiple of 4.
 int zero_async(void* p, size_t bytes, hipStream_t s);
+int zero2_async(void* p1, size_t bytes1, void* p2, size_t bytes2, hipStream_t s);   // two 16-B aligned ranges, one launch
 int copy_words_async(void* dst, const void* src, int n_words, hipStream_t s);
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
@@ -130,6 +131,8 @@ struct rg_frontier {
   int32_t* prefix_tmp = nullptr;     // [B][W]
   int32_t* scan_scratch = nullptr;
   int32_t* counters = nullptr;       // device: [0]=N (int32), [1]=error flag, [2..3]=E (uint64), [4]=N of level 0, [64..]=per-level snapshots
+  mutable bool queues_clean = false; // the heads are known to be zero on the stream (the hop's last kernel cleared them): the next walk
+                                     // launch skips its own clearing launch
   int32_t* queues = nullptr;         // device: the 8 per-XCD work-queue heads of the walks, RG_QSTRIDE ints apart (one 128-B line each:
                                      // returning atomics to ONE line serialise at ~50 per microsecond chip-wide, measured on the word-parallel
                                      // walk, whatever the number of distinct words in it)

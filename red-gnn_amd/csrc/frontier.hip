@@ -33,9 +33,21 @@ __global__ void reset_level0_kernel(const int32_t* __restrict__ q_sub, int B, in
   }
 }
 
-// end of a hop: snapshot {N, error flag, E} of the new level for rg_frontier_level_counts
-__global__ void snapshot_kernel(int32_t* __restrict__ counters, int slot) {
-  if (threadIdx.x < 4) counters[slot + threadIdx.x] = counters[threadIdx.x];
+// end of a hop: snapshot {N, error flag, E} of the new level for rg_frontier_level_counts (per-level slot) and for
+// rg_frontier_expand's read-back (slot 8), then clear the E accumulator for the next hop's prologue and the work-queue heads
+// for the layer kernel that follows (one launch less per walk)
+__device__ __forceinline__ void end_of_hop(int32_t* __restrict__ counters, int32_t* __restrict__ queues, int slot, int t) {
+  if (t < 4) {
+    const int32_t v = counters[t];
+    if (slot >= 0) counters[slot + t] = v;
+    counters[8 + t] = v;
+  }
+  if (t >= 8 && t < 16) queues[(t - 8) * RG_QSTRIDE] = 0;
+}
+__global__ void snapshot_kernel(int32_t* __restrict__ counters, int32_t* __restrict__ queues, int slot) {
+  end_of_hop(counters, queues, slot, threadIdx.x);
+  __syncthreads();
+  if (threadIdx.x == 0) { counters[2] = 0; counters[3] = 0; }
 }
 
 __global__ void reset_nodes_kernel(const int32_t* __restrict__ nodes, int64_t n, int B, int n_ent, int BW,
@@ -80,15 +92,17 @@ __global__ __launch_bounds__(256) void hop_or_kernel(const int4* __restrict__ vr
   }
 }
 
-// ---- E = sum over visited (b,h) of outdeg(h) -----------------------------------------------------
-__global__ __launch_bounds__(256) void count_edges_kernel(const int32_t* __restrict__ out_ptr,
-                                                          const uint32_t* __restrict__ oldT, int n_ent, int BW,
-                                                          unsigned long long* total) {
+// ---- hop prologue: E += sum over visited (b,h) of outdeg(h) (the accumulator is cleared by the previous hop's end / the
+// reset), and the new level's entity-major bitmap is zeroed for hop_or_kernel's atomicOr ------------------------------------
+__global__ __launch_bounds__(256) void hop_prologue_kernel(const int32_t* __restrict__ out_ptr,
+                                                           const uint32_t* __restrict__ oldT, uint32_t* __restrict__ newT,
+                                                           int n_ent, int BW, unsigned long long* total) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long v = 0;
   if (i < (int64_t)n_ent * BW) {
     const int h = (int)(i / BW);
     v = (unsigned long long)(out_ptr[h + 1] - out_ptr[h]) * __popc(oldT[i]);
+    newT[i] = 0u;
   }
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
   __shared__ unsigned long long ws[4];
@@ -198,6 +212,87 @@ __global__ void edge_fill_kernel(const int32_t* __restrict__ nodes_new, int64_t 
   }
 }
 
+// ---- small batches: transpose + popcount scan + pack + end of hop (+ node list) in ONE workgroup --------------------------
+// At the reference's evaluation batch sizes (n_tbatch = 50: 50 x 94 words on family) the five kernels above are a few
+// microseconds of work each and ~7 us of launch latency each inside a replayed HIP graph; the batch-major words fit LDS.
+constexpr int SMALL_T = 1024;
+constexpr int SMALL_MAX_WORDS = 12288;      // [B][W] words in LDS (48 KB)
+
+__global__ __launch_bounds__(SMALL_T) void build_level_small_kernel(const uint32_t* __restrict__ bitsT, int n_ent, int B, int BW, int W,
+                                                                    int n_pairs, int2* __restrict__ bm_new, const int2* __restrict__ bm_old,
+                                                                    int32_t* __restrict__ counters, int32_t* __restrict__ queues, int slot,
+                                                                    int32_t* __restrict__ nodes, int32_t* __restrict__ prev_idx,
+                                                                    int32_t* __restrict__ old_new) {
+  extern __shared__ uint32_t words[];       // [B * W]
+  __shared__ int32_t wsum[SMALL_T / 64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int nw = B * W;
+  for (int task = wv; task < BW * n_pairs; task += SMALL_T / 64) {       // as transpose_kernel, one (batch word, entity pair) per wave
+    const int bw = task / n_pairs, pair = task - bw * n_pairs;
+    const int e = pair * 64 + lane;
+    const uint32_t v = (e < n_ent) ? bitsT[(int64_t)e * BW + bw] : 0u;
+    uint32_t lo = 0, hi = 0;
+#pragma unroll
+    for (int b = 0; b < 32; ++b) {
+      const unsigned long long m = __ballot((v >> b) & 1u);
+      if (lane == b) { lo = (uint32_t)m; hi = (uint32_t)(m >> 32); }
+    }
+    const int batch = bw * 32 + lane;
+    if (lane < 32 && batch < B) {
+      words[batch * W + 2 * pair] = lo;
+      if (2 * pair + 1 < W) words[batch * W + 2 * pair + 1] = hi;
+    }
+  }
+  __syncthreads();
+  const int per = (nw + SMALL_T - 1) / SMALL_T;
+  const int beg = min((int)threadIdx.x * per, nw), end = min(beg + per, nw);
+  int32_t sum = 0;
+  for (int i = beg; i < end; ++i) sum += __popc(words[i]);
+  int32_t inc = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int32_t t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) wsum[wv] = inc;
+  __syncthreads();
+  int32_t pre = inc - sum, total = 0;
+  for (int w = 0; w < SMALL_T / 64; ++w) {
+    const int32_t x = wsum[w];
+    if (w < wv) pre += x;
+    total += x;
+  }
+  for (int i = beg; i < end; ++i) {
+    uint32_t w = words[i];
+    bm_new[i] = make_int2((int)w, pre);
+    if (nodes || prev_idx || old_new) {
+      const int b = i / W, e0 = (i - b * W) * 32;
+      uint32_t ow = 0; int op = 0;
+      if ((prev_idx || old_new) && bm_old) { const int2 o = bm_old[i]; ow = (uint32_t)o.x; op = o.y; }
+      int idx = pre;
+      for (uint32_t rest = w; rest; rest &= rest - 1, ++idx) {
+        const int pos = __ffs((int)rest) - 1;
+        if (nodes) reinterpret_cast<int2*>(nodes)[idx] = make_int2(b, e0 + pos);
+        const int prev = ((ow >> pos) & 1u) ? op + __popc(ow & ((1u << pos) - 1u)) : -1;
+        if (prev_idx) prev_idx[idx] = prev;
+        if (old_new && prev >= 0) old_new[prev] = idx;
+      }
+    }
+    pre += __popc(w);
+  }
+  // end of hop (cf. end_of_hop): N is this kernel's total, the error flag and E were left by earlier kernels
+  const int t = threadIdx.x;
+  if (t < 4) {
+    const int32_t v = t == 0 ? total : counters[t];
+    if (t == 0) counters[0] = total;
+    if (slot >= 0) counters[slot + t] = v;
+    counters[8 + t] = v;
+  }
+  if (t >= 8 && t < 16) queues[(t - 8) * RG_QSTRIDE] = 0;
+  __syncthreads();
+  if (t == 0) { counters[2] = 0; counters[3] = 0; }
+}
+
 __global__ void set_last_kernel(int32_t* row_ptr, int64_t n, const int32_t* total) { row_ptr[n] = *total; }
 
 size_t ws_layout(int32_t n_ent, int32_t B, int32_t n_levels, size_t* off /*[8]*/) {
@@ -281,7 +376,8 @@ int rg_frontier_reset(rg_frontier* f, const int32_t* q_sub, void* stream) {
   RG_CHECK(f && q_sub, "rg_frontier_reset: NULL argument");
   hipStream_t s = (hipStream_t)stream;
   f->level = 0; f->tcur = 0; f->n_edges = 0;
-  if (rg::zero_async(f->bitsT[0], (size_t)f->n_ent * f->BW * 4, s) || rg::zero_async(f->counters, 1024, s)) return 1;
+  if (rg::zero2_async(f->bitsT[0], rg::align_up((size_t)f->n_ent * f->BW * 4, 16), f->counters, 1024, s)) return 1;
+  f->queues_clean = false;
   const int64_t nw = (int64_t)f->B * f->W;
   hipLaunchKernelGGL(reset_level0_kernel, dim3(rg::ceil_div(nw, 256)), dim3(256), 0, s, q_sub, f->B, f->n_ent, f->BW, f->W,
                      f->bitsT[0], f->bm[0], f->counters);
@@ -294,7 +390,8 @@ int rg_frontier_reset_nodes(rg_frontier* f, const int32_t* nodes, int64_t n, voi
   RG_CHECK(f && (nodes || n == 0) && n >= 0, "rg_frontier_reset_nodes: bad argument");
   hipStream_t s = (hipStream_t)stream;
   f->level = 0; f->tcur = 0; f->n_edges = 0;
-  if (rg::zero_async(f->bitsT[0], (size_t)f->n_ent * f->BW * 4, s) || rg::zero_async(f->counters, 1024, s)) return 1;
+  if (rg::zero2_async(f->bitsT[0], rg::align_up((size_t)f->n_ent * f->BW * 4, 16), f->counters, 1024, s)) return 1;
+  f->queues_clean = false;
   if (n > 0) {
     hipLaunchKernelGGL(reset_nodes_kernel, dim3(rg::ceil_div(n, 256)), dim3(256), 0, s, nodes, n, f->B, f->n_ent, f->BW,
                        f->bitsT[0], f->counters);
@@ -306,28 +403,41 @@ int rg_frontier_reset_nodes(rg_frontier* f, const int32_t* nodes, int64_t n, voi
   return 0;
 }
 
-// enqueue one expansion: bitsT[tcur] -> bitsT[tcur^1] -> bm[level+1]; N and E of the new level are left in counters[0], [2..3]
-// and snapshotted into counters[64 + 8*level ..] for rg_frontier_level_counts
-static int enqueue_expand(rg_frontier* f, const rg_graph* g, hipStream_t s) {
+// enqueue one expansion: bitsT[tcur] -> bitsT[tcur^1] -> bm[level+1]; N and E of the new level are left in counters[8], [10..11]
+// and snapshotted into counters[64 + 8*level ..] for rg_frontier_level_counts; the work-queue heads are left zeroed.
+// nodes / prev_idx (optional): the new level's node list as rg_frontier_nodes writes it, fused into the same launch for small batches.
+static int enqueue_expand(rg_frontier* f, const rg_graph* g, hipStream_t s, int32_t* nodes = nullptr, int32_t* prev_idx = nullptr) {
   const uint32_t* oldT = f->bitsT[f->tcur];
   uint32_t* newT = f->bitsT[f->tcur ^ 1];
   int WL = 1;
   while (WL < f->BW && WL < 64) WL <<= 1;
-  if (rg::zero_async(&f->counters[2], 8, s)) return 1;
-  hipLaunchKernelGGL(count_edges_kernel, dim3(rg::ceil_div((int64_t)f->n_ent * f->BW, 256)), dim3(256), 0, s, g->out_ptr,
-                     oldT, f->n_ent, f->BW, (unsigned long long*)&f->counters[2]);
+  hipLaunchKernelGGL(hop_prologue_kernel, dim3(rg::ceil_div((int64_t)f->n_ent * f->BW, 256)), dim3(256), 0, s, g->out_ptr,
+                     oldT, newT, f->n_ent, f->BW, (unsigned long long*)&f->counters[2]);
   RG_LAUNCH_CHECK();
-  if (rg::zero_async(newT, (size_t)f->n_ent * f->BW * 4, s)) return 1;
   hipLaunchKernelGGL(hop_or_kernel, dim3(rg::ceil_div(g->in_vr.n, 4)), dim3(256), 0, s, g->in_vr.rows, g->in_vr.n, g->in_hr,
                      oldT, newT, f->BW, WL);
   RG_LAUNCH_CHECK();
   f->tcur ^= 1;
   f->level += 1;
-  if (build_level(f, s)) return 1;
-  if (f->level < RG_MAX_LEVELS) {
-    hipLaunchKernelGGL(snapshot_kernel, dim3(1), dim3(64), 0, s, f->counters, 64 + 8 * f->level);
+  const int slot = f->level < RG_MAX_LEVELS ? 64 + 8 * f->level : -1;
+  const int64_t nw = (int64_t)f->B * f->W;
+  const int2* bm_old = f->bm_of(f->level - 1);
+  if (nw <= SMALL_MAX_WORDS) {
+    hipLaunchKernelGGL(build_level_small_kernel, dim3(1), dim3(SMALL_T), (size_t)nw * 4, s, f->bitsT[f->tcur], f->n_ent, f->B, f->BW,
+                       f->W, (f->W + 1) / 2, f->bm[f->level % f->n_levels], bm_old, f->counters, f->queues, slot, nodes, prev_idx,
+                       (int32_t*)nullptr);
     RG_LAUNCH_CHECK();
+  } else {
+    if (build_level(f, s)) return 1;
+    hipLaunchKernelGGL(snapshot_kernel, dim3(1), dim3(64), 0, s, f->counters, f->queues, slot);
+    RG_LAUNCH_CHECK();
+    if (nodes || prev_idx) {
+      hipLaunchKernelGGL(emit_nodes_kernel, dim3(rg::ceil_div(nw * 32, 256)), dim3(256), 0, s, f->bm_of(f->level), bm_old, f->B, f->W,
+                         nodes, prev_idx, (int32_t*)nullptr);
+      RG_LAUNCH_CHECK();
+    }
   }
+  f->queues_clean = true;
   return 0;
 }
 
@@ -338,15 +448,15 @@ int rg_frontier_expand(rg_frontier* f, const rg_graph* g, int64_t* counts_host, 
   hipStream_t s = (hipStream_t)stream;
   const int64_t n_old = f->n_nodes[f->level % f->n_levels];
   if (enqueue_expand(f, g, s)) return 1;
-  RG_HIP(hipMemcpyAsync(f->counts_pinned, f->counters, 32, hipMemcpyDeviceToHost, s));
+  RG_HIP(hipMemcpyAsync(f->counts_pinned, f->counters, 64, hipMemcpyDeviceToHost, s));
   RG_HIP(hipStreamSynchronize(s));
   const int32_t* c32 = (const int32_t*)f->counts_pinned;
   RG_CHECK(c32[1] == 0, "rg_frontier_expand: a start node had batch or entity id out of range");
   RG_CHECK(f->level != 1 || n_old < 0 || c32[4] == n_old, "rg_frontier_expand: %lld start nodes given but %d distinct (duplicates?)",
            (long long)n_old, c32[4]);
-  const int64_t n_new = c32[0];
+  const int64_t n_new = c32[8];           // the hop's end left {N, flag, E} in slot 8 (and cleared the E accumulator)
   int64_t e;
-  memcpy(&e, &c32[2], 8);
+  memcpy(&e, &c32[10], 8);
   f->n_nodes[f->level % f->n_levels] = n_new;
   f->n_edges = e;
   if (counts_host) { counts_host[0] = n_new; counts_host[1] = e; counts_host[2] = n_old; counts_host[3] = f->level; }
@@ -354,11 +464,16 @@ int rg_frontier_expand(rg_frontier* f, const rg_graph* g, int64_t* counts_host, 
 }
 
 int rg_frontier_expand_async(rg_frontier* f, const rg_graph* g, void* stream) {
+  return rg_frontier_expand_nodes_async(f, g, nullptr, nullptr, stream);
+}
+
+int rg_frontier_expand_nodes_async(rg_frontier* f, const rg_graph* g, int32_t* nodes_out, int32_t* prev_idx_out, void* stream) {
   RG_CHECK(f && g, "rg_frontier_expand_async: NULL argument");
   RG_CHECK(f->level >= 0, "rg_frontier_expand_async: call rg_frontier_reset first");
   RG_CHECK(g->n_ent == f->n_ent, "rg_frontier_expand_async: graph has %d entities, frontier %d", g->n_ent, f->n_ent);
   RG_CHECK(f->level + 1 < RG_MAX_LEVELS, "rg_frontier_expand_async: at most %d levels", RG_MAX_LEVELS - 1);
-  if (enqueue_expand(f, g, (hipStream_t)stream)) return 1;
+  RG_CHECK(!nodes_out || ((uintptr_t)nodes_out & 7) == 0, "rg_frontier_expand_nodes_async: nodes_out must be 8-byte aligned");
+  if (enqueue_expand(f, g, (hipStream_t)stream, nodes_out, prev_idx_out)) return 1;
   f->n_nodes[f->level % f->n_levels] = -1;      // unknown on the host: the layer calls take their n as a capacity hint
   f->n_edges = -1;
   return 0;

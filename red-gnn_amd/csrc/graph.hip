@@ -125,6 +125,24 @@ int zero_async(void* p, size_t bytes, hipStream_t s) {
   return 0;
 }
 
+__global__ void zero2_quads_kernel(uint4* __restrict__ p1, int64_t n1, uint4* __restrict__ p2, int64_t n2) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n1 + n2; i += stride) {
+    if (i < n1) p1[i] = make_uint4(0u, 0u, 0u, 0u);
+    else p2[i - n1] = make_uint4(0u, 0u, 0u, 0u);
+  }
+}
+
+int zero2_async(void* p1, size_t bytes1, void* p2, size_t bytes2, hipStream_t s) {
+  if ((((uintptr_t)p1 | (uintptr_t)p2) & 15) != 0 || ((bytes1 | bytes2) & 15) != 0) return zero_async(p1, bytes1, s) || zero_async(p2, bytes2, s);
+  const int64_t n = (int64_t)((bytes1 + bytes2) / 16);
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(zero2_quads_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(n, 256), 4096)), dim3(256), 0, s, (uint4*)p1,
+                     (int64_t)(bytes1 / 16), (uint4*)p2, (int64_t)(bytes2 / 16));
+  RG_LAUNCH_CHECK();
+  return 0;
+}
+
 int copy_words_async(void* dst, const void* src, int n_words, hipStream_t s) {
   RG_CHECK(n_words > 0 && n_words <= 256, "copy_words_async: %d words", n_words);
   hipLaunchKernelGGL(copy_words_kernel, dim3(1), dim3(256), 0, s, (uint32_t*)dst, (const uint32_t*)src, n_words);

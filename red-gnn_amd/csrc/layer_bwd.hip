@@ -596,7 +596,7 @@ extern "C" int rg_layer_bwd(const rg_frontier* f, const rg_graph* g, int32_t lev
   if (n_old == 0) return grad_a_q ? rg::launch_aq_sum(f->bm_of(level - 1), f->W, f->B, f->n_ent, 0, grad_a_s, ap, grad_a_q, (hipStream_t)stream) : 0;
   BwdArgs A;
   A.walk.n_items = n_items; A.walk.n_vrows = g->out_vr.n; A.walk.n_slots = g->out_vr.n_slots; A.walk.vrows = g->out_vr.rows;
-  A.walk.bm_test = f->bm_of(level - 1); A.walk.W = f->W; A.walk.queues = f->queues;
+  A.walk.bm_test = f->bm_of(level - 1); A.walk.W = f->W; A.walk.queues = f->queues; f->queues_clean = false;
   A.out_rt = g->out_rt; A.out_pk = g->out_pk;
   A.bm_new = f->bm_of(level); A.W = f->W;
   A.hidden = (const float4*)hidden; A.rela = (const float4*)rela; A.ld4 = ld / 4;
@@ -625,7 +625,7 @@ extern "C" int rg_layer_bwd(const rg_frontier* f, const rg_graph* g, int32_t lev
   // relation gradient, relation-major (see drel_kernel)
   DrelArgs D;
   D.walk.n_items = (int64_t)f->B * g->rel_vr.n; D.walk.n_vrows = g->rel_vr.n; D.walk.n_slots = 0; D.walk.vrows = g->rel_vr.rows;
-  D.walk.bm_test = nullptr; D.walk.W = f->W; D.walk.queues = f->queues;
+  D.walk.bm_test = nullptr; D.walk.W = f->W; D.walk.queues = f->queues; f->queues_clean = false;
   RG_CHECK(D.walk.n_items / 8 + ((int64_t)1 << 26) < ((int64_t)1 << 31), "rg_layer_bwd: relation work space too large for 32-bit queue tickets");
   D.rel_ht = g->rel_ht; D.bm_old = bm_old; D.bm_new = f->bm_of(level); D.W = f->W;
   D.a_s = (const float4*)a_s; D.a_r = (const float4*)a_r; D.a_q = (const float4*)a_q;

@@ -22,7 +22,11 @@ static int plan_walk(const rg_frontier* f, const rg_graph* g, int32_t level, int
   const bool short_rows = (double)g->n_fact < 12.0 * (double)g->n_ent;
   if (!tiny && !short_rows && (double)n_edges >= 0.4 * candidates) return 1;
   const double group_bytes = (double)n_old * ld * sizeof(float) / f->BW;      // source rows of one bitmap word's queries
-  return group_bytes <= 3.0 * (1 << 20) ? 2 : (group_bytes <= 6.0 * (1 << 20) ? 3 : 4);
+  int code = group_bytes <= 3.0 * (1 << 20) ? 2 : (group_bytes <= 6.0 * (1 << 20) ? 3 : 4);
+  // small batches: fewer items than the chip has wave slots -> the launch lasts as long as its heaviest item; smaller query groups
+  // (more, lighter items) shorten that critical path (family, 50 queries: 800 items of ~170 edges -> 3200 of ~43)
+  while (code < 4 && (int64_t)f->BW * (1 << (code - 2)) * g->in_pk_packs.n < 8192) ++code;
+  return code;
 }
 
 extern "C" int rg_layer_fwd_plan(const rg_frontier* f, const rg_graph* g, int32_t level, int64_t n_old, int64_t n_new,
@@ -70,7 +74,7 @@ extern "C" int rg_layer_fwd(const rg_frontier* f, const rg_graph* g, int32_t lev
     W.bm_old = A.bm_old; W.bm_new = A.bm_new;
     W.hidden = A.hidden; W.rela = A.rela; W.ld4 = A.ld4; W.a_s = A.a_s; W.a_r = A.a_r; W.a_q = A.a_q;
     W.w_alpha = w_alpha; W.b_alpha = b_alpha; W.attn_dim = attn_dim; W.n_rela_rows = g->n_rela_rows;
-    W.agg = A.agg; W.partial = A.partial; W.queues = f->queues;
+    W.agg = A.agg; W.partial = A.partial; W.queues = f->queues; W.queues_clean = A.walk.queues_clean;
     // a ticket is a returning atomic: about 200 edges' worth of items each (light items: hop 0; heavy ones are taken one by one)
     const int64_t n_e = level == f->level ? f->n_edges : -1;
     const int64_t by_work = n_e < 0 ? 2 : 200 * W.n_items / std::max<int64_t>(n_e, 1);

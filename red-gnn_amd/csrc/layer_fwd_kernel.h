@@ -255,7 +255,7 @@ int launch3(const FwdArgs& A, size_t lds, int B, const rg_vrows& vr, hipStream_t
   if (lds > 64 * 1024) RG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int per_cu = lds <= 53 * 1024 ? 3 : (lds <= 80 * 1024 ? 2 : 1);
   const int grid = rg::walk_grid(A.walk.n_items, BLOCK, G, DENSE, per_cu, KPG);
-  if (rg::zero_async(A.walk.queues, RG_QUEUE_BYTES, s)) return 1;
+  if (!A.walk.queues_clean && rg::zero_async(A.walk.queues, RG_QUEUE_BYTES, s)) return 1;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds, s, A);
   RG_LAUNCH_CHECK();
   return launch_combine(A, B, vr, s);
@@ -319,6 +319,8 @@ inline int fill_common(const char* who, const rg_frontier* f, const rg_graph* g,
   RG_CHECK(n_items / 8 + ((int64_t)1 << 26) < ((int64_t)1 << 31), "%s: work space too large for 32-bit queue tickets", who);
   A->walk.n_items = n_items; A->walk.n_vrows = g->in_vr.n; A->walk.n_slots = g->in_vr.n_slots; A->walk.vrows = g->in_vr.rows;
   A->walk.bm_test = f->bm_of(level); A->walk.W = f->W; A->walk.queues = f->queues;
+  A->walk.queues_clean = f->queues_clean;      // (left by the hop's last kernel; any walk launch dirties them)
+  f->queues_clean = false;
   A->in_hr = g->in_hr; A->in_pk = g->in_pk;
   A->bm_old = f->bm_of(level - 1); A->bm_new = f->bm_of(level); A->W = f->W;
   A->ld4 = ld / 4; A->attn_dim = attn_dim; A->n_rela_rows = g->n_rela_rows; A->rela_in_lds = 0;

@@ -30,6 +30,7 @@ struct WpArgs {
   uint8_t* written;           // [B * n_slots]: set where a partial sum was stored (zeroed by the caller)
   int32_t* queues;            // 8 heads, RG_QSTRIDE ints apart, zeroed by the launcher
   int32_t ipt;                // items per queue ticket
+  bool queues_clean;          // host side: the heads are already zero on the stream
 };
 
 // launches the kernel (and nothing else: the caller runs combine_kernel for cut rows, as after the per-query walk)

@@ -312,7 +312,7 @@ int launch4(const WpArgs& A, size_t lds, hipStream_t s) {
   if (lds > 64 * 1024) RG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int per_cu = lds <= 80 * 1024 ? 2 : 1;
   const int grid = (int)std::max<int64_t>(std::min<int64_t>(rg::ceil_div(A.n_items, WP_WAVES * A.ipt), 256 * per_cu), 1);
-  if (rg::zero_async(A.queues, RG_QUEUE_BYTES, s)) return 1;
+  if (!A.queues_clean && rg::zero_async(A.queues, RG_QUEUE_BYTES, s)) return 1;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(WP_BLOCK), lds, s, A);
   RG_LAUNCH_CHECK();
   return 0;

@@ -70,3 +70,67 @@ extern "C" int rg_rank(const float* scores, int32_t batch, int32_t n_ent, const 
   RG_LAUNCH_CHECK();
   return 0;
 }
+
+// ---- hoisted attention tables of all layers in one launch (include/redgnn.h: rg_attn_tables) ---------------------------------
+namespace {
+constexpr int RG_MAX_LAYERS = 16;
+struct TablesArgs {
+  const float* rela[RG_MAX_LAYERS];
+  const float* Wr[RG_MAX_LAYERS];
+  const float* Wqr[RG_MAX_LAYERS];
+  const float* bqr[RG_MAX_LAYERS];
+  const int64_t* q_rel;
+  float* a_r; float* a_q; float* rela_pad;
+  int n_layer, n_rows, batch, d, ld, attn, ap;
+};
+
+// one thread per output element: [l][row][j] of a_r (rows = relations) and a_q (rows = queries), then rela_pad's elements
+__global__ void attn_tables_kernel(TablesArgs A) {
+  const int64_t per_layer_a = (int64_t)(A.n_rows + A.batch) * A.ap;
+  const int64_t n_a = per_layer_a * A.n_layer;
+  const int64_t n_pad = A.rela_pad ? (int64_t)A.n_layer * A.n_rows * A.ld : 0;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_a) {
+    const int l = (int)(i / per_layer_a);
+    const int64_t k = i - (int64_t)l * per_layer_a;
+    const int row = (int)(k / A.ap), j = (int)(k - (int64_t)row * A.ap);
+    const bool is_q = row >= A.n_rows;
+    float acc = 0.f;
+    if (j < A.attn) {
+      const int r = is_q ? (int)A.q_rel[row - A.n_rows] : row;
+      const float* x = A.rela[l] + (int64_t)r * A.d;
+      const float* w = (is_q ? A.Wqr[l] : A.Wr[l]) + (int64_t)j * A.d;
+      for (int c = 0; c < A.d; ++c) acc = fmaf(x[c], w[c], acc);
+      if (is_q) acc += A.bqr[l][j];
+    }
+    if (is_q) A.a_q[((int64_t)l * A.batch + (row - A.n_rows)) * A.ap + j] = acc;
+    else A.a_r[((int64_t)l * A.n_rows + row) * A.ap + j] = acc;
+  } else if (i < n_a + n_pad) {
+    const int64_t k = i - n_a;
+    const int c = (int)(k % A.ld);
+    const int64_t lr = k / A.ld;
+    const int l = (int)(lr / A.n_rows), r = (int)(lr - (int64_t)l * A.n_rows);
+    A.rela_pad[k] = c < A.d ? A.rela[l][(int64_t)r * A.d + c] : 0.f;
+  }
+}
+}  // namespace
+
+extern "C" int rg_attn_tables(int32_t n_layer, int32_t n_rela_rows, int32_t batch, int32_t d, int32_t ld, int32_t attn_dim, int32_t ap,
+                              const float* const* rela, const float* const* Wr, const float* const* Wqr, const float* const* bqr,
+                              const int64_t* q_rel, float* a_r_out, float* a_q_out, float* rela_pad_out, void* stream) {
+  RG_CHECK(n_layer >= 1 && n_layer <= RG_MAX_LAYERS, "rg_attn_tables: n_layer=%d not in 1..%d", n_layer, RG_MAX_LAYERS);
+  RG_CHECK(rela && Wr && Wqr && bqr && q_rel && a_r_out && a_q_out, "rg_attn_tables: NULL argument");
+  RG_CHECK(n_rela_rows > 0 && batch > 0 && d > 0 && ld >= d && attn_dim > 0 && ap >= attn_dim, "rg_attn_tables: bad shape");
+  RG_CHECK(ld == d || rela_pad_out, "rg_attn_tables: rela_pad_out needed when ld != d");
+  TablesArgs A;
+  for (int l = 0; l < n_layer; ++l) {
+    RG_CHECK(rela[l] && Wr[l] && Wqr[l] && bqr[l], "rg_attn_tables: NULL pointer for layer %d", l);
+    A.rela[l] = rela[l]; A.Wr[l] = Wr[l]; A.Wqr[l] = Wqr[l]; A.bqr[l] = bqr[l];
+  }
+  A.q_rel = q_rel; A.a_r = a_r_out; A.a_q = a_q_out; A.rela_pad = ld == d ? nullptr : rela_pad_out;
+  A.n_layer = n_layer; A.n_rows = n_rela_rows; A.batch = batch; A.d = d; A.ld = ld; A.attn = attn_dim; A.ap = ap;
+  const int64_t n = (int64_t)(n_rela_rows + batch) * ap * n_layer + (A.rela_pad ? (int64_t)n_layer * n_rela_rows * ld : 0);
+  hipLaunchKernelGGL(attn_tables_kernel, dim3((unsigned)rg::ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, A);
+  RG_LAUNCH_CHECK();
+  return 0;
+}

@@ -539,7 +539,7 @@ extern "C" int rg_tlayer_bwd(const rg_frontier* f, const rg_graph* g, int32_t le
   if (n_old == 0) return grad_a_q ? rg::launch_aq_sum(f->bm_of(level - 1), f->W, f->B, f->n_ent, 0, grad_a_s, ap, grad_a_q, (hipStream_t)stream) : 0;
   TBwdArgs A;
   A.walk.n_items = n_items; A.walk.n_vrows = g->out_vr.n; A.walk.n_slots = g->out_vr.n_slots; A.walk.vrows = g->out_vr.rows;
-  A.walk.bm_test = f->bm_of(level - 1); A.walk.W = f->W; A.walk.queues = f->queues;
+  A.walk.bm_test = f->bm_of(level - 1); A.walk.W = f->W; A.walk.queues = f->queues; f->queues_clean = false;
   A.out_rt = g->out_rt; A.out_time = g->out_time; A.q_time = q_time;
   A.bm_new = f->bm_of(level); A.W = f->W;
   A.hidden_dir = (const float4*)hidden_dir; A.rela_dir = (const float4*)rela_dir; A.time_dir = (const float4*)time_dir;
@@ -569,7 +569,7 @@ extern "C" int rg_tlayer_bwd(const rg_frontier* f, const rg_graph* g, int32_t le
   K.a_s = (const float4*)a_s; K.a_r = (const float4*)a_r; K.a_q = (const float4*)a_q;
   K.w_alpha = w_alpha; K.b_alpha = b_alpha; K.attn_dim = attn_dim; K.n_rela_rows = g->n_rela_rows; K.n_time = g->n_time; K.ld4 = ld4;
   K.grad_agg = (const float4*)grad_agg;
-  K.walk.n_slots = 0; K.walk.bm_test = nullptr; K.walk.W = f->W; K.walk.queues = f->queues;
+  K.walk.n_slots = 0; K.walk.bm_test = nullptr; K.walk.W = f->W; K.walk.queues = f->queues; f->queues_clean = false;
   K.walk.n_items = (int64_t)f->B * g->rel_vr.n; K.walk.n_vrows = g->rel_vr.n; K.walk.vrows = g->rel_vr.rows;
   RG_CHECK(K.walk.n_items / 8 + ((int64_t)1 << 26) < ((int64_t)1 << 31), "rg_tlayer_bwd: relation work space too large for 32-bit queue tickets");
   K.ht = g->rel_ht; K.aux = g->rel_tm; K.g_table = grad_rela_dir;

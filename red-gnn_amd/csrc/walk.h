@@ -24,6 +24,7 @@ struct WalkArgs {
   const int2* bm_test;
   int W;
   int32_t* queues;   // 8 heads, RG_QSTRIDE ints apart: item offsets inside each eighth, zeroed before the launch
+  bool queues_clean = false;   // host side: the heads are already zero on the stream (rg_frontier::queues_clean)
 };
 
 // DENSE walks take KPG items per lane group and block step: 1 for graphs of long rows (C2: 34 entries per row),

@@ -143,6 +143,12 @@ class Frontier:
         self.level += 1
         self.n_new = self.n_old = self.n_edges = -1
 
+    def expand_nodes_async(self, graph, nodes, prev):
+        """expand_async + nodes_into in one library call (rg_frontier_expand_nodes_async: one fused launch for small batches)."""
+        _lib.check(_lib.lib().rg_frontier_expand_nodes_async(self.handle, graph.handle, _lib.ptr(nodes), _lib.ptr(prev), _lib.stream_ptr()))
+        self.level += 1
+        self.n_new = self.n_old = self.n_edges = -1
+
     def count_ptr(self):
         """Device address of the newest level's node count (int32), for dense_fwd_dev."""
         return C.c_void_p(_lib.lib().rg_frontier_count_ptr(self.handle))
@@ -238,7 +244,8 @@ class FrontierPool:
         self.max_keys, self.pool = max_keys, {}
 
     def get(self, n_ent, batch, n_levels, device):
-        key = (n_ent, batch, n_levels, str(device))
+        # per stream: forwards enqueued on different streams (the evaluator's lanes) run concurrently on the device
+        key = (n_ent, batch, n_levels, str(device), torch.cuda.current_stream(device).cuda_stream)
         frs = self.pool.get(key)
         if frs is None:
             if len(self.pool) >= self.max_keys:
@@ -456,6 +463,26 @@ def dense_train_bwd(g_h, ws, x, mask, keep, act, W_h, w_ih, w_hh):
                                              {"idd": 0, "relu": 1, "tanh": 2}[act], _lib.ptr(c(W_h)), _lib.ptr(c(w_ih)), _lib.ptr(c(w_hh)),
                                              _lib.ptr(dgi), _lib.ptr(dgh), _lib.ptr(dpre), _lib.ptr(dagg), _lib.ptr(dh0), _lib.stream_ptr()))
     return dgi, dgh, dpre, dagg, dh0
+
+
+def attn_tables(layers, q_rel, d, ld, attn_dim, ap):
+    """Hoisted attention tables of all layers in ONE launch (rg_attn_tables): [(a_r [2R+1, ap], a_q [B, ap], rela padded to ld)] per layer.
+    ``layers``: the GNNLayer modules (rela_embed, Wr_attn, Wqr_attn read in place: no stacking copies)."""
+    L, dev = len(layers), q_rel.device
+    n_rows, B = layers[0].rela_embed.weight.shape[0], q_rel.numel()
+    a_r = torch.empty((L, n_rows, ap), dtype=torch.float32, device=dev)
+    a_q = torch.empty((L, B, ap), dtype=torch.float32, device=dev)
+    rela_p = torch.empty((L, n_rows, ld), dtype=torch.float32, device=dev) if ld != d else None
+    arr = lambda ts: (C.c_void_p * L)(*[t.data_ptr() for t in ts])
+    for l in layers:
+        for t in (l.rela_embed.weight, l.Wr_attn.weight, l.Wqr_attn.weight, l.Wqr_attn.bias):
+            assert t.is_contiguous() and t.dtype == torch.float32 and t.is_cuda
+    assert q_rel.dtype == torch.int64 and q_rel.is_contiguous()
+    _lib.check(_lib.lib().rg_attn_tables(L, n_rows, B, d, ld, attn_dim, ap, arr([l.rela_embed.weight for l in layers]),
+                                         arr([l.Wr_attn.weight for l in layers]), arr([l.Wqr_attn.weight for l in layers]),
+                                         arr([l.Wqr_attn.bias for l in layers]), _lib.ptr(q_rel), _lib.ptr(a_r), _lib.ptr(a_q),
+                                         _lib.ptr(rela_p), _lib.stream_ptr()))
+    return [(a_r[i], a_q[i], rela_p[i] if rela_p is not None else layers[i].rela_embed.weight) for i in range(L)]
 
 
 def rank(scores, ans_ptr, ans_idx, filt_ptr, filt_idx):

@@ -263,14 +263,12 @@ class _GraphedInference:
         d, a, ld, ap = m.hidden_dim, m.attn_dim, self.ld, self.ap
         fr.reset(self.q_sub)
         hidden, a_s = self.hid[1], self.a_s[1]
-        hidden[:n].zero_()                                    # hidden == 0 at layer 0 (models.py:74)
-        a_s[:n].zero_()
-        self.scores.zero_()                                   # models.py:87
+        # hidden == 0 at layer 0 (models.py:74), scores_all = 0 (models.py:87): one multi-tensor launch
+        torch._foreach_zero_([hidden[:n], a_s[:n], self.scores])
         tables = m.inference_tables(self.q_rel, ld, ap)
         for i in range(m.n_layer):
             layer = m.gnn_layers[i]
-            fr.expand_async(graph)
-            fr.nodes_into(self.nodes, self.prev)
+            fr.expand_nodes_async(graph, self.nodes, self.prev)
             a_r, a_q, rela_p = tables[i]
             n_hint, walk = self.hints[i]
             engine.layer_fwd_into(fr, graph, fr.level, n_hint, hidden, rela_p, d, a_s, a_r, a_q,
@@ -397,27 +395,17 @@ class RED_GNN_trans(nn.Module):
         return scores_all.view(n, n_ent)
 
     def inference_tables(self, q_rel, ld, ap):
-        """Per-layer attention tables of an inference forward for ALL layers in a dozen launches (they are tiny, so their launch
-        count - not their work - is what a small batch pays for): a_r[i] = Wr_i(rela_i) [2R+1, ap], a_q[i] = Wqr_i(rela_i[q_rel])
-        + b_i [B, ap] (models.py:33,36, the three attention Linear layers hoisted), rela_i padded to ld columns."""
-        d, a = self.hidden_dim, self.attn_dim
-        layers = self.gnn_layers
-        rela = torch.stack([l.rela_embed.weight for l in layers])                               # [L, 2R+1, d]
-        wr = torch.stack([l.Wr_attn.weight for l in layers])                                     # [L, a, d]
-        wq = torch.stack([l.Wqr_attn.weight for l in layers])
-        bq = torch.stack([l.Wqr_attn.bias for l in layers])                                      # [L, a]
-        if ap != a:
-            wr, wq, bq = F.pad(wr, (0, 0, 0, ap - a)), F.pad(wq, (0, 0, 0, ap - a)), F.pad(bq, (0, ap - a))
-        a_r = torch.bmm(rela, wr.transpose(1, 2))                                                # [L, 2R+1, ap]
-        a_q = torch.baddbmm(bq[:, None, :], rela[:, q_rel], wq.transpose(1, 2))                  # [L, B, ap]
-        rela_p = F.pad(rela, (0, ld - d)) if ld != d else rela
-        return [(a_r[i], a_q[i], rela_p[i]) for i in range(self.n_layer)]
+        """Per-layer attention tables of an inference forward for ALL layers in one launch (they are tiny, so their launch count -
+        not their work - is what a small batch pays for): a_r[i] = Wr_i(rela_i) [2R+1, ap], a_q[i] = Wqr_i(rela_i[q_rel]) + b_i
+        [B, ap] (models.py:33,36, the three attention Linear layers hoisted), rela_i padded to ld columns."""
+        return engine.attn_tables(list(self.gnn_layers), q_rel.contiguous(), self.hidden_dim, ld, self.attn_dim, ap)
 
     def _forward_graphed(self, graph, q_sub, q_rel, n, device):
         """Replay (or, on the third call with the same graph and batch size, capture) the forward as a HIP graph.
         Returns None when this call should run eagerly: the first two calls of a shape (the eager run also provides the
         per-hop sizes that pick the kernels' walks), or shapes whose full-grid buffers would be too large."""
-        key = (id(graph), n, str(device))
+        # one captured graph (with its own full-grid buffers) per stream: the evaluator's lanes replay concurrently
+        key = (id(graph), n, str(device), torch.cuda.current_stream(device).cuda_stream)
         g = self._graphed.get(key)
         if g is not None and g.key_ptr != self.W_final.weight.data_ptr():        # parameters were re-allocated (.to(), ...)
             g = None
@@ -436,7 +424,7 @@ class RED_GNN_trans(nn.Module):
             # memory budget for the capacity-sized buffers
             need = _GraphedInference.bytes_needed(n, graph.n_ent, ld, ap)
             held = sum(_GraphedInference.bytes_needed(v.n, v.graph.n_ent, v.ld, v.ap) for v in self._graphed.values())
-            if len(self._graphed) >= 8 or held + need > 2 * _GraphedInference.MAX_BYTES:
+            if len(self._graphed) >= 32 or held + need > 2 * _GraphedInference.MAX_BYTES:
                 self._graphed.clear()
             try:
                 g = self._graphed[key] = _GraphedInference(self, graph, n, device, hints)
