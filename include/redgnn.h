@@ -42,6 +42,15 @@ int rg_version(void);
  * inside every CSR row so sums are reproducible. */
 int rg_graph_create(int32_t n_ent, int32_t n_rel, const int32_t* triples_host, int64_t n,
                     int add_inverse, rg_graph** out);
+/* The same graph from a DEVICE triple array (int32 [n,3]), built on the device: the per-epoch rebuild of shuffle_train
+ * (load_data.py:152-164: permute facts + train, re-split 3:1, load_graph) without moving the triples or the CSR arrays through the host.
+ * Every array of the result equals rg_graph_create's on the same triples.  Synchronises `stream` (it returns counts). */
+int rg_graph_create_device(int32_t n_ent, int32_t n_rel, const int32_t* triples_dev, int64_t n,
+                           int add_inverse, void* stream, rg_graph** out);
+/* copy the word-parallel walk's packs back (tests): sizes first (out arrays NULL), then ent int32 [n_packs*128, 2], pack int32 [n_packs, 4],
+ * rows int32 [n_vrows, 2]; and the virtual rows of the CSR-by-tail, int32 [n_vrows, 4]. */
+int rg_graph_export_packs(const rg_graph* g, int32_t* n_packs, int32_t* n_vrows, int32_t* ent_host, int32_t* pack_host, int32_t* rows_host,
+                          int32_t* vrows_host);
 /* temporal graph (T-RED-GNN interpolation): replaces the per-call coo_matrix build of
  * Temporal/interpolation/model_cuda.py:121-126 over the quadruple array of graph.py:34-49.
  * quads: HOST int32 [n,4] = (head, rel, tail, time id), used as given (the reference's graph array already

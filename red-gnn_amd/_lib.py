@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_PKG, "libredgnn.so")
 # every symbol include/redgnn.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "rg_last_error", "rg_version",
-    "rg_graph_create", "rg_tgraph_create", "rg_tgraph_create_excluding", "rg_graph_destroy", "rg_graph_n_fact", "rg_graph_export",
+    "rg_graph_create", "rg_graph_create_device", "rg_graph_export_packs", "rg_tgraph_create", "rg_tgraph_create_excluding", "rg_graph_destroy", "rg_graph_n_fact", "rg_graph_export",
     "rg_frontier_workspace_bytes", "rg_frontier_create", "rg_frontier_destroy", "rg_frontier_reset",
     "rg_frontier_reset_nodes", "rg_frontier_expand", "rg_frontier_nodes", "rg_frontier_edges_scratch_bytes", "rg_frontier_edges",
     "rg_layer_fwd_scratch_bytes", "rg_layer_fwd", "rg_layer_fwd_plan", "rg_tlayer_fwd", "rg_layer_bwd_scratch_bytes", "rg_layer_bwd", "rg_tlayer_bwd_scratch_bytes", "rg_tlayer_bwd", "rg_dense_fwd_supported", "rg_dense_fwd", "rg_dense_fwd_dev", "rg_dense_train_fwd", "rg_dense_train_bwd", "rg_rank",
@@ -43,6 +43,8 @@ def lib():
     L.rg_last_error.restype = C.c_char_p
     L.rg_version.restype = C.c_int
     L.rg_graph_create.argtypes = [i32, i32, vp, i64, C.c_int, C.POINTER(vp)]
+    L.rg_graph_create_device.argtypes = [i32, i32, vp, i64, C.c_int, vp, C.POINTER(vp)]
+    L.rg_graph_export_packs.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), vp, vp, vp, vp]
     L.rg_tgraph_create.argtypes = [i32, i32, i32, vp, i64, C.POINTER(vp)]
     L.rg_tgraph_create_excluding.argtypes = [i32, i32, i32, vp, i64, vp, i64, C.POINTER(vp)]
     L.rg_graph_destroy.argtypes = [vp]

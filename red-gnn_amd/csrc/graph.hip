@@ -461,4 +461,15 @@ int rg_graph_export(const rg_graph* g, int32_t* out_ptr, int32_t* out_rt, int32_
   return 0;
 }
 
+int rg_graph_export_packs(const rg_graph* g, int32_t* n_packs, int32_t* n_vrows, int32_t* ent, int32_t* pack, int32_t* rows, int32_t* vrows) {
+  RG_CHECK(g != nullptr, "rg_graph_export_packs: graph is NULL");
+  if (n_packs) *n_packs = g->in_pk_packs.n;
+  if (n_vrows) *n_vrows = g->in_vr.n;
+  if (ent && g->in_pk_packs.n) RG_HIP(hipMemcpy(ent, g->in_pk_packs.ent, (size_t)g->in_pk_packs.n * RG_PACK * sizeof(int2), hipMemcpyDeviceToHost));
+  if (pack && g->in_pk_packs.n) RG_HIP(hipMemcpy(pack, g->in_pk_packs.pack, (size_t)g->in_pk_packs.n * sizeof(int4), hipMemcpyDeviceToHost));
+  if (rows && g->in_pk_packs.n) RG_HIP(hipMemcpy(rows, g->in_pk_packs.rows, (size_t)g->in_vr.n * sizeof(int2), hipMemcpyDeviceToHost));
+  if (vrows) RG_HIP(hipMemcpy(vrows, g->in_vr.rows, (size_t)g->in_vr.n * sizeof(int4), hipMemcpyDeviceToHost));
+  return 0;
+}
+
 }  // extern "C"

@@ -48,6 +48,35 @@ class Graph:
         self.handle = h
         self.n_fact = int(_lib.lib().rg_graph_n_fact(h))
 
+    @classmethod
+    def from_device(cls, n_ent, n_rel, triples_dev, add_inverse=True):
+        """The same graph built on the device from a device int32 [n,3] tensor (rg_graph_create_device): the per-epoch rebuild of
+        shuffle_train without a host round trip of the triples."""
+        self = cls.__new__(cls)
+        self.device = _require_gpu(triples_dev.device)
+        assert triples_dev.dtype == torch.int32 and triples_dev.dim() == 2 and triples_dev.shape[1] == 3
+        trip = triples_dev.contiguous()
+        self.n_ent, self.n_rel = int(n_ent), int(n_rel)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().rg_graph_create_device(self.n_ent, self.n_rel, _lib.ptr(trip), trip.shape[0], 1 if add_inverse else 0,
+                                                         _lib.stream_ptr(), C.byref(h)))
+        self.handle = h
+        self.n_fact = int(_lib.lib().rg_graph_n_fact(h))
+        return self
+
+    def export_packs(self):
+        """(vrows [n_vrows,4], ent [n_packs*128,2], pack [n_packs,4], rows [n_vrows,2]) of the word-parallel walk as numpy — for tests."""
+        L = _lib.lib()
+        n_packs, n_vrows = C.c_int32(), C.c_int32()
+        _lib.check(L.rg_graph_export_packs(self.handle, C.byref(n_packs), C.byref(n_vrows), None, None, None, None))
+        vr = np.empty((n_vrows.value, 4), np.int32)
+        ent = np.empty((n_packs.value * 128, 2), np.int32)
+        pack = np.empty((n_packs.value, 4), np.int32)
+        rows = np.empty((n_vrows.value, 2), np.int32)
+        _lib.check(L.rg_graph_export_packs(self.handle, None, None, _lib.ptr(ent), _lib.ptr(pack), _lib.ptr(rows), _lib.ptr(vr)))
+        return vr, ent, pack, rows
+
     def export(self):
         """(out_ptr, out_rel_tail[n_fact,2], in_ptr, in_head_rel[n_fact,2]) as numpy — for tests."""
         op = np.empty(self.n_ent + 1, np.int32)

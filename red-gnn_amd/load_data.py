@@ -120,7 +120,17 @@ class DataLoader:
     @property
     def graph(self):
         if self._graph is None:
-            self._graph = Graph(self.n_ent, self.n_rel, self._graph_base, add_inverse=True, device=self.device)
+            perm = self.__dict__.pop("_graph_perm", None)
+            if perm is not None and torch.cuda.is_available():
+                # shuffle_train's re-split on the device: the triples of facts + train live there (uploaded once); an epoch moves
+                # only the permutation, and rg_graph_create_device builds the CSRs where they are used
+                all_dev = self.__dict__.get("_all_triple_dev")
+                if all_dev is None:
+                    all_dev = self._all_triple_dev = torch.as_tensor(self._all_triple, dtype=torch.int32).to(self.device)
+                idx = torch.as_tensor(perm, dtype=torch.int64).to(self.device)
+                self._graph = Graph.from_device(self.n_ent, self.n_rel, all_dev.index_select(0, idx))
+            else:
+                self._graph = Graph(self.n_ent, self.n_rel, self._graph_base, add_inverse=True, device=self.device)
         return self._graph
 
     @property
@@ -211,11 +221,15 @@ class DataLoader:
 
     def shuffle_train(self):
         """load_data.py:152-164: re-split facts/train 3:1 and rebuild the training graph."""
-        all_triple = np.concatenate([self.fact_triple, self.train_triple], axis=0)
-        n_all = len(all_triple)
-        all_triple = all_triple[np.random.permutation(n_all)]
-        facts, train = all_triple[:n_all * 3 // 4], all_triple[n_all * 3 // 4:]
+        if "_all_triple" not in self.__dict__:       # the reference permutes the ORIGINAL facts + train concatenation every epoch
+            self._all_triple = np.concatenate([self.fact_triple, self.train_triple], axis=0)
+        n_all = len(self._all_triple)
+        order = np.random.permutation(n_all)
+        all_triple = self._all_triple[order]
+        n_f = n_all * 3 // 4
+        facts, train = all_triple[:n_f], all_triple[n_f:]
         self.fact_data = self.double_triple(facts)
         self.train_data = self.double_triple(train)
         self.n_train = len(self.train_data)
         self.load_graph(facts)
+        self._graph_perm = order[:n_f]               # the training graph is built on the device from the resident triples (see .graph)

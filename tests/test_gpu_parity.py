@@ -698,6 +698,69 @@ def _ids(n_ent, n_rel, facts, train=None, test=None):
                 test=z if test is None else np.asarray(test, np.int64).reshape(-1, 3))
 
 
+@pytest.mark.parametrize("case", ["tiny", "hubs", "C2", "C3", "no_triples"])
+def test_device_graph_build_equals_host_build(case):
+    """rg_graph_create_device (the graph of shuffle_train's re-split, built where it is used) against rg_graph_create on the same
+    triples: both CSRs, the length-sorted virtual rows and the word-parallel walk's packs are equal array for array; the model
+    gives bitwise the same scores on either."""
+    from red_gnn_amd.engine import Graph
+    from red_gnn_amd.synthetic import make_shape, make_synthetic_kg
+    rng = np.random.default_rng(5)
+    if case in ("C2", "C3"):
+        kg = make_shape(case)
+        n_ent, n_rel, trip = kg.n_ent, kg.n_rel, np.concatenate([kg.facts, kg.train], 0)
+    elif case == "no_triples":
+        n_ent, n_rel, trip = 37, 2, np.zeros((0, 3), np.int64)
+    else:
+        n_ent, n_rel, m = (50, 4, 300) if case == "tiny" else (400, 7, 9000)
+        h, t = rng.integers(0, n_ent, m), rng.integers(0, n_ent, m)
+        if case == "hubs":
+            t[: m // 3] = 11                      # an in-row cut into > 20 segments
+            h[m // 3: m // 2] = 5                 # an out-row cut into segments
+        trip = np.stack([h, rng.integers(0, n_rel, m), t], 1)
+        trip = np.concatenate([trip, trip[:7]], 0)                     # duplicates stay parallel edges
+    trip = trip[rng.permutation(len(trip))]
+    g_h = Graph(n_ent, n_rel, trip)
+    g_d = Graph.from_device(n_ent, n_rel, torch.as_tensor(trip, dtype=torch.int32).cuda())
+    assert g_h.n_fact == g_d.n_fact == 2 * len(trip) + n_ent
+    for a, b, name in zip(g_h.export(), g_d.export(), ("out_ptr", "out_rel_tail", "in_ptr", "in_head_rel")):
+        assert np.array_equal(a, b), name
+    for a, b, name in zip(g_h.export_packs(), g_d.export_packs(), ("in_vrows", "pack_entries", "packs", "pack_rows")):
+        assert a.shape == b.shape and np.array_equal(a, b), name
+
+
+def test_shuffle_train_builds_its_graph_on_the_device():
+    """DataLoader.shuffle_train (load_data.py:152-164): same split as the reference's formula for the same numpy seed, the training
+    graph (built by rg_graph_create_device from the resident triples) equals the host build of that split, and training-mode
+    forwards on it match the oracle on the re-split facts."""
+    from red_gnn_amd.engine import Graph
+    from red_gnn_amd.load_data import DataLoader
+    from red_gnn_amd.synthetic import make_synthetic_kg
+    kg = make_synthetic_kg(300, 5, 3000, seed=23)
+    ids = dict(n_ent=kg.n_ent, n_rel=kg.n_rel, facts=kg.facts, train=kg.train, valid=kg.valid, test=kg.test)
+    loader = DataLoader(ids=ids, verbose=False)
+    model = _random_model(loader, 2, 32, 5, "relu", seed=6)
+    allt = np.concatenate([kg.facts, kg.train], 0)
+    for epoch in range(2):                                     # every epoch permutes the ORIGINAL concatenation (the reference keeps it)
+        np.random.seed(100 + epoch)
+        loader.shuffle_train()
+        np.random.seed(100 + epoch)
+        perm = np.random.permutation(len(allt))
+        facts, train = allt[perm][: len(allt) * 3 // 4], allt[perm][len(allt) * 3 // 4:]
+        assert np.array_equal(loader.train_data, orc.double_triple(train, kg.n_rel))
+        assert np.array_equal(loader.fact_data, orc.double_triple(facts, kg.n_rel))
+        g_ref = Graph(kg.n_ent, kg.n_rel, facts)
+        for a, b in zip(loader.graph.export(), g_ref.export()):
+            assert np.array_equal(a, b)
+        trip = loader.train_data[:9]
+        with torch.no_grad():
+            s = model(trip[:, 0], trip[:, 1], mode="train").cpu().numpy()
+        p = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        og = orc.OracleGraph(orc.double_triple(facts, kg.n_rel), kg.n_ent, kg.n_rel)
+        ref = orc.forward(p, og, trip[:, 0], trip[:, 1], 2, act="relu").numpy()
+        np.testing.assert_allclose(s, ref, rtol=RTOL, atol=ATOL)
+
+
 @pytest.mark.parametrize("n_ent,B", [(1, 1), (31, 1), (33, 3), (64, 33), (97, 65)])
 def test_edge_shapes_vs_oracle(n_ent, B):
     """n_ent / batch sizes around the 32-bit word and 64-lane boundaries, isolated entities (identity edge only),
