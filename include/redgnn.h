@@ -166,6 +166,23 @@ int rg_tlayer_fwd(const rg_frontier* f, const rg_graph* g, int32_t level, int64_
                   const float* w_alpha, const float* b_alpha, int32_t attn_dim,
                   float* agg_out, void* scratch_dev, size_t scratch_bytes, void* stream);
 
+/* ---- temporal EXTRAPOLATION (Temporal/extrapolation/model_cuda_new_embedding.py:135-265): every query sees only the data rows of
+ * its own time window, `self.dataset[time_offset_list[begin]:time_offset_list[cur_t]]` (:167-171), plus one self-loop per entity.
+ * The graph is an rg_tgraph whose quadruples carry, in the time field, the index of the edge's row in the time-sorted data array
+ * (self-loops: any value >= n_data).  rg_frontier_set_window gives the frontier the per-query row windows [win_lo[b], win_hi[b])
+ * (device int32 [batch], caller-owned, NULL = no windows): rg_frontier_expand* then follow only edges valid for the query, and
+ * rg_xlayer_fwd is the layer (:186-226) over those edges.  All edges lie in the past, so one direction matrix applies (past_linear):
+ * hidden_p = W_past h [N_old, ld], rela_p = W_past rela [n_rela_rows, ld], time_p [n_tab, ld] = W_past time_embed(delta) for
+ * delta = 0..n_tab-1; delta(edge, b) = q_time[b] - row_time[data row] (self-loops: q_time[b] - loop_time[b]), clamped to n_tab - 1.
+ * Attention as rg_tlayer_fwd.  Forward only. */
+int rg_frontier_set_window(rg_frontier* f, const int32_t* win_lo_dev, const int32_t* win_hi_dev, int32_t n_data);
+int rg_xlayer_fwd(const rg_frontier* f, const rg_graph* g, int32_t level, int64_t n_new, const int32_t* q_time,
+                  const int32_t* loop_time, const int32_t* row_time, int32_t n_data,
+                  const float* hidden_p, const float* rela_p, const float* time_p, int32_t n_tab, int32_t d, int32_t ld,
+                  const float* a_s, const float* a_r, const float* a_q, int32_t ap,
+                  const float* w_alpha, const float* b_alpha, int32_t attn_dim,
+                  float* agg_out, void* scratch_dev, size_t scratch_bytes, void* stream);
+
 /* ---- layer backward: adjoint of rg_layer_fwd (autograd of models.py:29-39) --------------------
  * grad_agg [N_new, ld].  grad_hidden [N_old, ld] and grad_a_s [N_old, ap] are WRITTEN (every row);
  * grad_rela [2R+1, ld], grad_a_r [2R+1, ap], grad_w_alpha [attn_dim], grad_b_alpha [1] are ACCUMULATED

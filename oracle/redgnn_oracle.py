@@ -219,6 +219,86 @@ def temporal_forward(p, quads, n_ent, heads, rels, times, n_layer, act, shared_t
     return score_all
 
 
+# --------------------------------------------------------------------------------------
+# temporal extrapolation  (Temporal/extrapolation/model_cuda_new_embedding.py:135-265, utils.py:692-699)
+# PARITY UNPINNED: that model file cannot be imported in the build container (torch_scatter, pyvis, rtdl_revisiting_models are
+# absent) and the reference holds no outputs of it; this is a line-by-line restatement, checked by nothing but reading.
+# --------------------------------------------------------------------------------------
+def get_time_offset_list(data, time_granularity=24):
+    """utils.py:692-699, literally (the loop; offsets of days without rows stay 0)."""
+    data = np.asarray(data)
+    max_time = max(data[:, 3] // time_granularity)
+    offset_list = np.zeros(max_time + 2, dtype=np.int32)
+    for idx, (_, _, _, t) in enumerate(data):
+        offset_list[t // time_granularity + 1] = idx
+    return offset_list
+
+
+def periodic_embedding(p, prefix, x, dtype=torch.float32):
+    """rtdl_num_embeddings.py:92-100,199-215 (the reference's edited PeriodicEmbeddings, one feature, lite=False): x [N,1] -> [N,d]."""
+    g = lambda k: _t(p[prefix + k], dtype)
+    x = x.to(dtype)
+    is_neg = (x < 0).unsqueeze(-1)
+    z = 2 * np.pi * g("periodic.weight") * x[..., None]
+    z = torch.cat([torch.cos(z), torch.sin(z)], -1)
+    neg = (z[..., None, :] @ g("linear_neg.weight")).squeeze(-2) + g("linear_neg.bias")
+    pos = (z[..., None, :] @ g("linear_pos.weight")).squeeze(-2) + g("linear_pos.bias")
+    return torch.relu(neg * is_neg + pos * (~is_neg)).squeeze(1)
+
+
+def extrap_forward(p, data, time_offset_list, time_granularity, n_ent, n_rel_true, src, rel, ts, n_layer, act, dtype=torch.float32,
+                   trace=None):
+    """T_RED_GNN.forward of the extrapolation setting (model_cuda_new_embedding.py:135-261) without the attention statistics.
+    Returns (score_all [B, n_ent], softmax over each query's visited entities [N], visited (batch, entity) [N,2])."""
+    data = np.asarray(data, dtype=np.int64).reshape(-1, 4)
+    src, rel, ts = (np.asarray(x, dtype=np.int64) for x in (src, rel, ts))
+    g = lambda k: _t(p[k], dtype)
+    acts = {"tanh": torch.tanh, "sigmoid": torch.sigmoid, "relu": torch.relu, "idd": lambda x: x,
+            "softplus": torch.nn.functional.softplus, "leakyrelu": torch.nn.functional.leaky_relu}
+    B = len(src)
+    d = g("linear_classifier.weight").shape[1]
+    cur_t = ts // time_granularity                                                         # :138
+    rows = []
+    for b in range(B):                                                                     # :165-176
+        begin = max(int(cur_t[b]) - 120, 0)
+        batch = data[time_offset_list[begin]:time_offset_list[cur_t[b]]]
+        loops = np.column_stack([np.arange(n_ent), np.full(n_ent, n_rel_true), np.arange(n_ent), np.full(n_ent, begin * time_granularity)])
+        batch = np.concatenate([loops, batch], 0)
+        rows.append(np.concatenate([np.full((len(batch), 1), b), batch], 1))
+    rel_all = np.concatenate(rows, 0).astype(np.int64)                                      # (batch, subject, relation, object, time)
+    key_all = rel_all[:, 0] * n_ent + rel_all[:, 1]
+    cur = np.stack([np.arange(B), src], 1)                                                 # :139
+    hidden = torch.zeros(B, d, dtype=dtype)
+    for i in range(n_layer):
+        cur_key = cur[:, 0] * n_ent + cur[:, 1]
+        sel = rel_all[np.isin(key_all, cur_key)]                                           # :186-189 (rows whose subject is in the frontier)
+        src_pos = torch.as_tensor(np.searchsorted(cur_key, sel[:, 0] * n_ent + sel[:, 1]))     # node_new_index[...] - 1 (cur is sorted)
+        b_idx = torch.as_tensor(sel[:, 0])
+        rela = g("rela_embed_layer.%d.weight" % i)
+        rel_t = torch.as_tensor(sel[:, 2])
+        delta = torch.as_tensor(cur_t)[b_idx] - torch.as_tensor(sel[:, 4] // time_granularity)   # :192
+        tau = periodic_embedding(p, "time_embed.", delta.reshape(-1, 1), dtype)           # :201
+        hs = hidden[src_pos]
+        msg = (hs + rela[rel_t] + tau) @ g("past_linear.weight").T                        # :203-205
+        att_in = torch.cat([hs, rela[rel_t], rela[torch.as_tensor(rel)][b_idx]], 1)        # :207
+        alpha = torch.sigmoid(torch.relu(att_in @ g("attention_1_layer.%d.weight" % i).T) @ g("attention_2_layer.%d.weight" % i).T)   # :208
+        new_key = sel[:, 0] * n_ent + sel[:, 3]                                            # :224 unique(batch, object), sorted
+        uk, inv = np.unique(new_key, return_inverse=True)
+        agg = torch.zeros(len(uk), d, dtype=dtype).index_add_(0, torch.as_tensor(inv), alpha * msg)     # :236 scatter sum
+        hidden = acts[act](agg)                                                            # :238
+        cur = np.stack([uk // n_ent, uk % n_ent], 1)
+        if trace is not None:
+            trace.append(dict(nodes=cur, n_edges=len(sel), hidden=hidden))
+    result = (hidden @ g("linear_classifier.weight").T + g("linear_classifier.bias")).reshape(-1)     # :244
+    score_all = torch.zeros(B, n_ent, dtype=dtype)
+    score_all[torch.as_tensor(cur[:, 0]), torch.as_tensor(cur[:, 1])] = result
+    seg = torch.as_tensor(cur[:, 0])
+    mx = torch.full((B,), float("-inf"), dtype=dtype).scatter_reduce(0, seg, result, "amax")
+    ex = torch.exp(result - mx[seg])
+    soft = ex / torch.zeros(B, dtype=dtype).index_add_(0, seg, ex)[seg]                    # :248 scatter_softmax
+    return score_all, soft, cur
+
+
 def loss_fn(scores, pos_tail):
     """base_model.py:58-60 — full-softmax cross entropy, restated literally.
 

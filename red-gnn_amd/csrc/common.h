@@ -131,6 +131,11 @@ struct rg_frontier {
   int32_t* prefix_tmp = nullptr;     // [B][W]
   int32_t* scan_scratch = nullptr;
   int32_t* counters = nullptr;       // device: [0]=N (int32), [1]=error flag, [2..3]=E (uint64), [4]=N of level 0, [64..]=per-level snapshots
+  // per-query data-row windows [win_lo[b], win_hi[b]) of the extrapolation setting (rg_frontier_set_window; caller-owned device arrays,
+  // NULL = none) and the number of data rows (edges whose row id is >= n_data are the always-valid self-loops)
+  const int32_t* win_lo = nullptr;
+  const int32_t* win_hi = nullptr;
+  int32_t win_n_data = 0;
   mutable bool queues_clean = false; // the heads are known to be zero on the stream (the hop's last kernel cleared them): the next walk
                                      // launch skips its own clearing launch
   int32_t* queues = nullptr;         // device: the 8 per-XCD work-queue heads of the walks, RG_QSTRIDE ints apart (one 128-B line each:

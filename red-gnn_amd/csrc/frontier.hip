@@ -92,6 +92,50 @@ __global__ __launch_bounds__(256) void hop_or_kernel(const int4* __restrict__ vr
   }
 }
 
+// ---- the hop under per-query time windows (temporal extrapolation): edge j = data row in_time[j] counts for query b only if
+// win_lo[b] <= row < win_hi[b] (rows >= n_data are the self-loops: always).  Same lane mapping as hop_or_kernel; the 32-query
+// mask of an (edge, word) pair is built from the window bounds only when the source has a bit in that word.  E (valid edges of
+// the hop) is counted here: the prologue's out-degree sum would count rows outside the windows.
+__global__ __launch_bounds__(256) void hop_or_window_kernel(const int4* __restrict__ vrows, int n_vrows, const int2* __restrict__ in_hr,
+                                                            const int32_t* __restrict__ in_row, const uint32_t* __restrict__ oldT,
+                                                            uint32_t* __restrict__ newT, int BW, int WL, int B, const int32_t* __restrict__ win_lo,
+                                                            const int32_t* __restrict__ win_hi, int n_data, unsigned long long* total) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (wave >= n_vrows) return;
+  const int4 row = vrows[wave];
+  const int t = row.x, beg = row.y, end = row.y + row.z;
+  const int wl = lane & (WL - 1);
+  const int el = lane / WL, EL = 64 / WL;
+  unsigned long long cnt = 0;
+  for (int w0 = 0; w0 < BW; w0 += WL) {
+    const int w = w0 + wl;
+    uint32_t acc = 0;
+    if (w < BW) {
+      for (int j = beg + el; j < end; j += EL) {
+        uint32_t v = oldT[(int64_t)in_hr[j].x * BW + w];
+        if (v) {
+          const int r = in_row[j];
+          if (r < n_data) {
+            uint32_t m = 0;
+            for (uint32_t rest = v; rest; rest &= rest - 1) {
+              const int bit = __ffs((int)rest) - 1, b = w * 32 + bit;
+              if (b < B && r >= win_lo[b] && r < win_hi[b]) m |= 1u << bit;
+            }
+            v = m;
+          }
+          acc |= v;
+          cnt += __popc(v);
+        }
+      }
+    }
+    for (int o = WL; o < 64; o <<= 1) acc |= __shfl_xor(acc, o, 64);
+    if (el == 0 && w < BW && acc) atomicOr(&newT[(int64_t)t * BW + w], acc);
+  }
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, 64);
+  if (lane == 0 && cnt) atomicAdd(total, cnt);
+}
+
 // ---- hop prologue: E += sum over visited (b,h) of outdeg(h) (the accumulator is cleared by the previous hop's end / the
 // reset), and the new level's entity-major bitmap is zeroed for hop_or_kernel's atomicOr ------------------------------------
 __global__ __launch_bounds__(256) void hop_prologue_kernel(const int32_t* __restrict__ out_ptr,
@@ -101,7 +145,7 @@ __global__ __launch_bounds__(256) void hop_prologue_kernel(const int32_t* __rest
   unsigned long long v = 0;
   if (i < (int64_t)n_ent * BW) {
     const int h = (int)(i / BW);
-    v = (unsigned long long)(out_ptr[h + 1] - out_ptr[h]) * __popc(oldT[i]);
+    if (out_ptr) v = (unsigned long long)(out_ptr[h + 1] - out_ptr[h]) * __popc(oldT[i]);
     newT[i] = 0u;
   }
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
@@ -386,6 +430,13 @@ int rg_frontier_reset(rg_frontier* f, const int32_t* q_sub, void* stream) {
   return 0;
 }
 
+int rg_frontier_set_window(rg_frontier* f, const int32_t* win_lo, const int32_t* win_hi, int32_t n_data) {
+  RG_CHECK(f != nullptr, "rg_frontier_set_window: frontier is NULL");
+  RG_CHECK((win_lo == nullptr) == (win_hi == nullptr) && n_data >= 0, "rg_frontier_set_window: give both bounds (or neither)");
+  f->win_lo = win_lo; f->win_hi = win_hi; f->win_n_data = n_data;
+  return 0;
+}
+
 int rg_frontier_reset_nodes(rg_frontier* f, const int32_t* nodes, int64_t n, void* stream) {
   RG_CHECK(f && (nodes || n == 0) && n >= 0, "rg_frontier_reset_nodes: bad argument");
   hipStream_t s = (hipStream_t)stream;
@@ -411,11 +462,17 @@ static int enqueue_expand(rg_frontier* f, const rg_graph* g, hipStream_t s, int3
   uint32_t* newT = f->bitsT[f->tcur ^ 1];
   int WL = 1;
   while (WL < f->BW && WL < 64) WL <<= 1;
-  hipLaunchKernelGGL(hop_prologue_kernel, dim3(rg::ceil_div((int64_t)f->n_ent * f->BW, 256)), dim3(256), 0, s, g->out_ptr,
-                     oldT, newT, f->n_ent, f->BW, (unsigned long long*)&f->counters[2]);
+  const bool windowed = f->win_lo != nullptr;
+  RG_CHECK(!windowed || g->in_time, "rg_frontier_expand: time windows are set but the graph carries no data-row ids (rg_tgraph_create)");
+  hipLaunchKernelGGL(hop_prologue_kernel, dim3(rg::ceil_div((int64_t)f->n_ent * f->BW, 256)), dim3(256), 0, s,
+                     windowed ? (const int32_t*)nullptr : g->out_ptr, oldT, newT, f->n_ent, f->BW, (unsigned long long*)&f->counters[2]);
   RG_LAUNCH_CHECK();
-  hipLaunchKernelGGL(hop_or_kernel, dim3(rg::ceil_div(g->in_vr.n, 4)), dim3(256), 0, s, g->in_vr.rows, g->in_vr.n, g->in_hr,
-                     oldT, newT, f->BW, WL);
+  if (windowed)
+    hipLaunchKernelGGL(hop_or_window_kernel, dim3(rg::ceil_div(g->in_vr.n, 4)), dim3(256), 0, s, g->in_vr.rows, g->in_vr.n, g->in_hr,
+                       g->in_time, oldT, newT, f->BW, WL, f->B, f->win_lo, f->win_hi, f->win_n_data, (unsigned long long*)&f->counters[2]);
+  else
+    hipLaunchKernelGGL(hop_or_kernel, dim3(rg::ceil_div(g->in_vr.n, 4)), dim3(256), 0, s, g->in_vr.rows, g->in_vr.n, g->in_hr,
+                       oldT, newT, f->BW, WL);
   RG_LAUNCH_CHECK();
   f->tcur ^= 1;
   f->level += 1;

@@ -60,6 +60,14 @@ struct FwdArgs {
   const int32_t* q_time;
   int n_time;
   const float4* time_tab;   // [3 * n_time][ld4]
+  // extrapolation variant (Temporal/extrapolation/model_cuda_new_embedding.py): in_time[c] = the data row of the edge (>= n_data: a
+  // self-loop), valid for query b only inside its row window [win_lo[b], win_hi[b]); every edge lies in the past: one direction,
+  // time_tab row = q_time[b] - row_time[data row]  (self-loops: q_time[b] - loop_time[b]), clamped to n_time - 1
+  const int32_t* win_lo;
+  const int32_t* win_hi;
+  const int32_t* row_time;
+  const int32_t* loop_time;
+  int n_data;
 };
 
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -111,8 +119,11 @@ __global__ __launch_bounds__(FWD_BLOCK, 6) void layer_fwd_kernel(FwdArgs A) {
       for (int k = 0; k < AP4; ++k) aq[k] = aq_p[k];
     }
     const int2* bm_row = A.bm_old + (int64_t)b * A.W;
-    int qt = 0;
-    if constexpr (TEMPORAL) qt = A.q_time[b];
+    int qt = 0, wlo = 0, whi = 0;
+    if constexpr (TEMPORAL) {
+      qt = A.q_time[b];
+      if (A.win_lo) { wlo = A.win_lo[b]; whi = A.win_hi[b]; }
+    }
     float4 acc = f4zero();
     for (int c0 = beg; c0 < end; c0 += G) {
       // ---- phase 1: one candidate in-edge per lane ---------------------------------------------
@@ -127,6 +138,12 @@ __global__ __launch_bounds__(FWD_BLOCK, 6) void layer_fwd_kernel(FwdArgs A) {
         const int2 wp = bm_row[hd >> 5];
         const uint32_t word = (uint32_t)wp.x, bit = hd & 31;
         valid = (word >> bit) & 1u;
+        if constexpr (TEMPORAL) {
+          if (A.win_lo && valid) {            // the edge's data row must lie inside the query's time window (self-loops always do)
+            const int row = A.in_time[c];
+            valid = row >= A.n_data || (row >= wlo && row < whi);
+          }
+        }
         if (valid) {
           s = wp.y + __popc(word & ((1u << bit) - 1u));
           float z = b_alpha;
@@ -146,11 +163,17 @@ __global__ __launch_bounds__(FWD_BLOCK, 6) void layer_fwd_kernel(FwdArgs A) {
           if constexpr (TEMPORAL) {
             // direction-specific linears hoisted per node / relation / |dt|: row = 3*id + dir, dir = past 0 / now 1 / future 2
             // (Temporal/interpolation/model_cuda.py:149-157)
-            const int dt = A.in_time[c] - qt;
-            const int dir = dt > 0 ? 2 : (dt == 0 ? 1 : 0);
-            s = s * 3 + dir;
-            r = dir * A.n_rela_rows + r;
-            trow = dir * A.n_time + (dt < 0 ? -dt : dt);
+            if (A.win_lo) {
+              const int row = A.in_time[c];
+              const int delta = qt - (row >= A.n_data ? A.loop_time[b] : A.row_time[row]);
+              trow = min(max(delta, 0), A.n_time - 1);
+            } else {
+              const int dt = A.in_time[c] - qt;
+              const int dir = dt > 0 ? 2 : (dt == 0 ? 1 : 0);
+              s = s * 3 + dir;
+              r = dir * A.n_rela_rows + r;
+              trow = dir * A.n_time + (dt < 0 ? -dt : dt);
+            }
           }
         }
       }
@@ -325,6 +348,7 @@ inline int fill_common(const char* who, const rg_frontier* f, const rg_graph* g,
   A->bm_old = f->bm_of(level - 1); A->bm_new = f->bm_of(level); A->W = f->W;
   A->ld4 = ld / 4; A->attn_dim = attn_dim; A->n_rela_rows = g->n_rela_rows; A->rela_in_lds = 0;
   A->in_time = nullptr; A->q_time = nullptr; A->n_time = 0; A->time_tab = nullptr;
+  A->win_lo = nullptr; A->win_hi = nullptr; A->row_time = nullptr; A->loop_time = nullptr; A->n_data = 0;
   return 0;
 }
 

@@ -159,6 +159,16 @@ class Frontier:
         self.level, self.n_new, self.n_old, self.n_edges = 0, nodes.shape[0], 0, 0
         self.generation += 1
 
+    def set_window(self, win_lo, win_hi, n_data):
+        """Per-query data-row windows of the extrapolation setting (rg_frontier_set_window); int32 device tensors [batch], kept alive here."""
+        if win_lo is None:
+            self._window = None
+            _lib.check(_lib.lib().rg_frontier_set_window(self.handle, None, None, 0))
+            return
+        assert win_lo.dtype == torch.int32 and win_hi.dtype == torch.int32 and win_lo.is_cuda and win_lo.numel() == self.batch == win_hi.numel()
+        self._window = (win_lo.contiguous(), win_hi.contiguous())
+        _lib.check(_lib.lib().rg_frontier_set_window(self.handle, _lib.ptr(self._window[0]), _lib.ptr(self._window[1]), int(n_data)))
+
     def expand(self, graph):
         """One hop.  Returns (n_new, n_edges, n_old); synchronises the stream once."""
         _lib.check(_lib.lib().rg_frontier_expand(self.handle, graph.handle, self._counts, _lib.stream_ptr()))
@@ -348,6 +358,23 @@ def tlayer_fwd(frontier, graph, level, n_new, q_time, hidden_dir, rela_dir, time
                                         _lib.ptr(rela_dir), _lib.ptr(time_dir), d, ld, _lib.ptr(a_s), _lib.ptr(a_r), _lib.ptr(a_q),
                                         ap, _lib.ptr(w_alpha), _lib.ptr(b_alpha), attn_dim, _lib.ptr(agg), _lib.ptr(scratch),
                                         nbytes, _lib.stream_ptr()))
+    return agg
+
+
+def xlayer_fwd(frontier, graph, level, n_new, q_time, loop_time, row_time, n_data, hidden_p, rela_p, time_p, d, a_s, a_r, a_q, w_alpha, b_alpha, attn_dim):
+    """Temporal-extrapolation fused message passing (rg_xlayer_fwd): agg [n_new, ld]."""
+    ld, ap = hidden_p.shape[1], a_s.shape[1]
+    for t in (hidden_p, rela_p, time_p, a_s, a_r, a_q, w_alpha, b_alpha):
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+    for t in (q_time, loop_time, row_time):
+        assert t.dtype == torch.int32 and t.is_cuda and t.is_contiguous()
+    agg = torch.empty((n_new, ld), dtype=torch.float32, device=hidden_p.device)
+    nbytes = _lib.lib().rg_layer_fwd_scratch_bytes(frontier.handle, graph.handle, ld)
+    scratch = frontier.scratch(nbytes)
+    _lib.check(_lib.lib().rg_xlayer_fwd(frontier.handle, graph.handle, level, n_new, _lib.ptr(q_time), _lib.ptr(loop_time), _lib.ptr(row_time),
+                                        int(n_data), _lib.ptr(hidden_p), _lib.ptr(rela_p), _lib.ptr(time_p), time_p.shape[0], d, ld,
+                                        _lib.ptr(a_s), _lib.ptr(a_r), _lib.ptr(a_q), ap, _lib.ptr(w_alpha), _lib.ptr(b_alpha), attn_dim,
+                                        _lib.ptr(agg), _lib.ptr(scratch), nbytes, _lib.stream_ptr()))
     return agg
 
 

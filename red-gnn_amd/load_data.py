@@ -21,11 +21,20 @@ class DataLoader:
     def __init__(self, task_dir=None, ids=None, device="cuda", verbose=True, cache_dir=None):
         self.task_dir = task_dir
         self.device = torch.device(device)
-        self.filters = defaultdict(set)
+        self._filters = defaultdict(set)
+        binary = None
         if ids is None and cache_dir is not None:
-            ids = self._cached_ids(task_dir, cache_dir)      # binary id cache of the parsed text
+            ids = self._cached_ids(task_dir, cache_dir)      # binary cache of the parsed text
         if ids is None:
             self._read_text(task_dir)
+        elif "valid_q" in ids:
+            # binary cache: id triples + the queries / answers / filter sets of valid and test as CSR lists (what the GPU ranker takes):
+            # none of the per-triple Python loops of the text path runs; the (h, r) -> tails dict is rebuilt only if somebody asks
+            binary = ids
+            self.n_ent, self.n_rel = int(ids["n_ent"]), int(ids["n_rel"])
+            as3 = lambda a: np.asarray(a, dtype=np.int64).reshape(-1, 3)
+            self.fact_triple, self.train_triple, self.valid_triple, self.test_triple = (as3(ids[k]) for k in ("facts", "train", "valid", "test"))
+            self._filters = None
         else:
             self.n_ent, self.n_rel = int(ids["n_ent"]), int(ids["n_rel"])
             self.fact_triple = self._register(ids["facts"])
@@ -43,18 +52,41 @@ class DataLoader:
         self.load_graph(self.fact_triple)                                               # :43
         self.load_test_graph(np.concatenate([self.fact_triple, self.train_triple], 0))  # :44
 
-        self.valid_q, self.valid_a = self.load_query(self.valid_data)
-        self.test_q, self.test_a = self.load_query(self.test_data)
+        if binary is not None:
+            self._csr_host = {}
+            for split in ("valid", "test"):
+                q, ap, ai = binary[split + "_q"], binary[split + "_ans_ptr"], binary[split + "_ans_idx"]
+                setattr(self, split + "_q", [(int(h), int(r)) for h, r in q])
+                setattr(self, split + "_a", [ai[ap[i]:ap[i + 1]] for i in range(len(q))])
+                self._csr_host[split] = (binary[split + "_filt_ptr"], binary[split + "_filt_idx"])
+        else:
+            self.valid_q, self.valid_a = self.load_query(self.valid_data)
+            self.test_q, self.test_a = self.load_query(self.test_data)
+            self._filters = {k: sorted(v) for k, v in self._filters.items()}
         self.n_train, self.n_valid, self.n_test = len(self.train_data), len(self.valid_q), len(self.test_q)
-        self.filters = {k: sorted(v) for k, v in self.filters.items()}
         self._frontiers = {}
         if verbose:
             print("n_train:", self.n_train, "n_valid:", self.n_valid, "n_test:", self.n_test)
 
     _FILES = ("entities.txt", "relations.txt", "facts.txt", "train.txt", "valid.txt", "test.txt")
 
+    @property
+    def filters(self):
+        """(h, r) -> sorted tails over all four splits (load_data.py:65-66).  Loaded from the binary cache it is rebuilt on first use."""
+        if self._filters is None:
+            self._filters = defaultdict(set)
+            for t in (self.fact_triple, self.train_triple, self.valid_triple, self.test_triple):
+                self._register(t)
+            self._filters = {k: sorted(v) for k, v in self._filters.items()}
+        return self._filters
+
+    @filters.setter
+    def filters(self, value):
+        self._filters = value
+
     def _cached_ids(self, task_dir, cache_dir):
-        """Parse the text files once; later runs load `<cache_dir>/<name>_ids.npz` while it is newer than every text file."""
+        """Parse the text files once; later runs load `<cache_dir>/<name>_ids.npz` while it is newer than every text file.
+        The file holds the id triples and, for valid and test, the queries with their answers and filter sets as CSR lists."""
         os.makedirs(cache_dir, exist_ok=True)
         path = os.path.join(cache_dir, os.path.basename(os.path.normpath(task_dir)) + "_ids.npz")
         newest = max(os.path.getmtime(os.path.join(task_dir, f)) for f in self._FILES)
@@ -63,8 +95,16 @@ class DataLoader:
         self._read_text(task_dir)
         ids = dict(n_ent=np.int64(self.n_ent), n_rel=np.int64(self.n_rel), facts=self.fact_triple, train=self.train_triple,
                    valid=self.valid_triple, test=self.test_triple)
+        filters = {k: sorted(v) for k, v in self._filters.items()}
+        ptr = lambda lists: np.concatenate([[0], np.cumsum([len(x) for x in lists])]).astype(np.int64)
+        cat = lambda lists: np.concatenate([np.asarray(x, dtype=np.int64) for x in lists]) if len(lists) else np.zeros(0, np.int64)
+        for split, trip in (("valid", self.valid_triple), ("test", self.test_triple)):
+            q, a = self.load_query(self.double_triple(trip))
+            fil = [filters[k] for k in q]
+            ids.update({split + "_q": np.asarray(q, dtype=np.int64).reshape(-1, 2), split + "_ans_ptr": ptr(a), split + "_ans_idx": cat(a),
+                        split + "_filt_ptr": ptr(fil), split + "_filt_idx": cat(fil)})
         np.savez_compressed(path, **ids)
-        self.filters = defaultdict(set)                     # rebuilt from the ids below
+        self._filters = defaultdict(set)                    # (the text parse above filled it; the binary path starts clean)
         return ids
 
     # ---- parsing (load_data.py:11-25, 58-67) ----------------------------------------------------
@@ -92,8 +132,8 @@ class DataLoader:
         """Every known (h,r,t) of any split goes into the filter sets (load_data.py:65-66)."""
         triples = np.asarray(triples, dtype=np.int64).reshape(-1, 3)
         for h, r, t in triples.tolist():
-            self.filters[(h, r)].add(t)
-            self.filters[(t, r + self.n_rel)].add(h)
+            self._filters[(h, r)].add(t)
+            self._filters[(t, r + self.n_rel)].add(h)
         return triples
 
     def double_triple(self, triples):
@@ -193,9 +233,14 @@ class DataLoader:
         if data not in cache:
             query, answer = (self.valid_q, self.valid_a) if data == "valid" else (self.test_q, self.test_a)
             ans = [np.sort(np.asarray(a)) for a in answer]                # np.nonzero order of utils.py:12-13
-            fil = [np.asarray(self.filters[(int(s), int(r))]) for s, r in query]
             ptr = lambda lists: np.concatenate([[0], np.cumsum([len(x) for x in lists])]).astype(np.int64)
             cat = lambda lists: np.concatenate(lists) if len(lists) else np.zeros(0, np.int64)
+            host = self.__dict__.get("_csr_host", {}).get(data)
+            if host is not None:                                          # the binary cache holds the filter lists as CSR already
+                fptr_h, fidx_h = host
+                fil = [fidx_h[fptr_h[i]:fptr_h[i + 1]] for i in range(len(query))]
+            else:
+                fil = [np.asarray(self.filters[(int(s), int(r))]) for s, r in query]
             to_dev = lambda a, dt: torch.as_tensor(np.asarray(a), dtype=dt).to(self.device)
             subs, rels = np.array([q[0] for q in query]), np.array([q[1] for q in query])
             cache[data] = (subs, rels, ptr(ans), to_dev(cat(ans), torch.int32), ptr(fil), to_dev(cat(fil), torch.int32),

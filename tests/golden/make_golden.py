@@ -366,10 +366,47 @@ def case_ranks(out_dir):
                         filters=filters.astype(np.uint8), ranks=ranks, perf=perf)
 
 
+def case_extrap_rank(out_dir):
+    """segment_rank_fil of the reference's Temporal/extrapolation/segment.py:346-387 (imports unmodified: numpy + torch only) on
+    segmented scores with exact ties, targets that some queries never reached, and filter sets that hide higher-scored entities."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_segment", "/root/reference/Temporal/extrapolation/segment.py")
+    seg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(seg)
+    rng = np.random.default_rng(7)
+    n_q, n_ent = 40, 60
+    ents, scores = [], []
+    for q in range(n_q):
+        k = int(rng.integers(1, 30))
+        e = np.sort(rng.choice(n_ent, k, replace=False))
+        v = np.round(rng.random(k), 1) if q % 3 == 0 else rng.random(k)           # exact ties in a third of the segments
+        ents.append(np.stack([np.full(k, q), e], 1)); scores.append(v)
+    entities = np.concatenate(ents, 0)
+    t = torch.tensor(np.concatenate(scores), dtype=torch.float32)
+    target = np.array([int(ents[q][rng.integers(0, len(ents[q])), 1]) if q % 5 else int((ents[q][-1, 1] + 1) % n_ent) for q in range(n_q)])
+    sub, pre, ts = rng.integers(0, n_ent, n_q), rng.integers(0, 5, n_q), rng.integers(0, 50, n_q) * 24
+    sp2o, spt2o = {}, {}
+    sp_lists, spt_lists = [], []
+    for q in range(n_q):
+        a = np.unique(np.concatenate([[target[q]], rng.choice(n_ent, int(rng.integers(0, 12)), replace=False)]))
+        b = np.unique(np.concatenate([[target[q]], rng.choice(a, int(rng.integers(0, len(a))), replace=False)]))
+        sp2o[(sub[q], pre[q])] = a; spt2o[(sub[q], pre[q], ts[q])] = b
+    for q in range(n_q):                      # (the dicts may have merged duplicate keys: store what the reference actually saw)
+        sp_lists.append(np.asarray(sp2o[(sub[q], pre[q])])); spt_lists.append(np.asarray(spt2o[(sub[q], pre[q], ts[q])]))
+    rank, found, rank_fil, rank_fil_t = seg.segment_rank_fil(t, entities, target, sp2o, spt2o, sub, pre, ts)
+    ptr = lambda ls: np.concatenate([[0], np.cumsum([len(x) for x in ls])]).astype(np.int64)
+    np.savez_compressed(os.path.join(out_dir, "extrap_rank.npz"), scores=t.numpy(), entities=entities, target=target, sub=sub, pre=pre, ts=ts,
+                        sp_ptr=ptr(sp_lists), sp_idx=np.concatenate(sp_lists), spt_ptr=ptr(spt_lists), spt_idx=np.concatenate(spt_lists),
+                        rank=rank, found=np.array(found), rank_fil=rank_fil, rank_fil_t=rank_fil_t)
+
+
 if __name__ == "__main__":
     out = HERE
     if sys.argv[1:] == ["temporal_train"]:      # regenerate only this case
         case_temporal_train(out)
+        sys.exit(0)
+    if sys.argv[1:] == ["extrap_rank"]:
+        case_extrap_rank(out)
         sys.exit(0)
     case_tiny(out)
     case_ranks(out)
@@ -379,6 +416,7 @@ if __name__ == "__main__":
     case_inductive(out)
     case_temporal(out)
     case_temporal_train(out)
+    case_extrap_rank(out)
     for f in sorted(os.listdir(out)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(out, f)))

@@ -633,6 +633,51 @@ def test_temporal_per_layer_tables_vs_oracle(d, a, act, n_layer):
     assert np.array_equal(s == 0, ref == 0)
 
 
+@pytest.mark.parametrize("d,a,act,n_layer,B", [(32, 5, "tanh", 3, 9), (64, 30, "relu", 2, 40), (20, 3, "idd", 2, 3)])
+def test_temporal_extrapolation_vs_oracle(d, a, act, n_layer, B):
+    """T-RED-GNN extrapolation (per-query 120-step time windows over ONE device graph, self-loops, past_linear only,
+    periodic time embedding, per-query softmax over the visited entities) against the oracle's restatement of
+    model_cuda_new_embedding.py:135-261 - parity UNPINNED (that file cannot be imported here).  The data have days without rows
+    (offset quirk of utils.py:692-699), queries older and younger than the window length, hub objects and duplicate rows."""
+    from red_gnn_amd import extrapolation as X
+    rng = np.random.default_rng(d + B)
+    n_ent, n_rel, n = 120, 6, 5000
+    days = np.sort(rng.choice(np.delete(np.arange(200), [0, 50, 51, 120]), n))
+    w = 1.0 / np.arange(1, n_ent + 1); w /= w.sum()
+    data = np.stack([rng.integers(0, n_ent, n), rng.integers(0, n_rel, n), rng.choice(n_ent, n, p=w), days * 24 + rng.integers(0, 24, n)], 1)
+    data = data[np.argsort(data[:, 3], kind="stable")]
+    data[10:14] = data[9]                                                        # duplicate rows stay parallel edges
+
+    class P:
+        pass
+
+    p = P()
+    p.n_ent, p.n_rel, p.data, p.time_granularity, p.hidden_dim, p.attn_dim, p.n_layer, p.act, p.device = n_ent, n_rel, data, 24, d, a, n_layer, act, "cuda"
+    torch.manual_seed(3)
+    model = X.T_RED_GNN(p).cuda().eval()
+    q = data[np.sort(rng.choice(np.arange(30, n), B, replace=False))]            # queries across the whole time range
+
+    class Q:
+        src_idx, rel_idx, ts = q[:, 0], q[:, 1], q[:, 3]
+
+    score_all, (soft, ents) = model(Q)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    otrace = []
+    ref_s, ref_soft, ref_ents = orc.extrap_forward(sd, data, orc.get_time_offset_list(data, 24), 24, n_ent, n_rel, q[:, 0], q[:, 1], q[:, 3],
+                                                   n_layer, act, trace=otrace)
+    assert np.array_equal(ents, ref_ents)
+    assert model.last_stats["n_edges"] == [t["n_edges"] for t in otrace]
+    np.testing.assert_allclose(score_all.cpu().numpy(), ref_s.numpy(), rtol=RTOL, atol=ATOL_H)
+    assert np.array_equal(score_all.cpu().numpy() == 0, ref_s.numpy() == 0)
+    np.testing.assert_allclose(soft.cpu().numpy(), ref_soft.numpy(), rtol=2e-4, atol=1e-7)
+    # the evaluation of main.py:404 on top: same ranks from either path's scores
+    sp2o = {(int(s), int(r)): np.unique(data[(data[:, 0] == s) & (data[:, 1] == r), 2]) for s, r in zip(q[:, 0], q[:, 1])}
+    spt2o = {(int(s), int(r), int(t)): np.unique(data[(data[:, 0] == s) & (data[:, 1] == r) & (data[:, 3] == t), 2]) for s, r, t in zip(q[:, 0], q[:, 1], q[:, 3])}
+    r1 = X.segment_rank_fil(soft, ents, q[:, 2], sp2o, spt2o, q[:, 0].tolist(), q[:, 1].tolist(), q[:, 3].tolist())
+    r2 = X.segment_rank_fil(ref_soft, ref_ents, q[:, 2], sp2o, spt2o, q[:, 0].tolist(), q[:, 1].tolist(), q[:, 3].tolist())
+    assert r1[1] == r2[1] and np.mean(r1[0] != r2[0]) <= 0.1 and np.mean(r1[2] != r2[2]) <= 0.1       # (near-ties may swap)
+
+
 def _grads(model):
     return {k: (v.grad.detach().cpu().numpy() if v.grad is not None else None) for k, v in model.named_parameters()}
 

@@ -275,5 +275,11 @@ def test_loader_id_cache_roundtrip():
         b = DataLoader(task, verbose=False, cache_dir=os.path.join(td, "cache"))
         c = DataLoader(task, verbose=False)
     for x in (a, b):
-        assert x.filters == c.filters and x.valid_q == c.valid_q and x.test_q == c.test_q
+        assert x._filters is None                                   # binary path: no per-triple Python loop ran ...
+        assert x.valid_q == c.valid_q and x.test_q == c.test_q
+        assert all(np.array_equal(p, q) for p, q in zip(x.test_a, c.test_a)) and all(np.array_equal(p, q) for p, q in zip(x.valid_a, c.valid_a))
         assert np.array_equal(x.fact_triple, c.fact_triple) and np.array_equal(x.train_data, c.train_data)
+        fptr, fidx = x._csr_host["test"]                            # ... the filter sets of the queries come as CSR lists
+        for i, (h, r) in enumerate(c.test_q):
+            assert list(fidx[fptr[i]:fptr[i + 1]]) == c.filters[(h, r)]
+        assert x.filters == c.filters                               # ... and the dict is rebuilt when asked for

@@ -141,3 +141,22 @@ def test_temporal_train_fixture_model_py():
     loss.backward()
     for k, v in p.items():
         np.testing.assert_allclose(v.grad.numpy(), fx["grad::" + k], rtol=1e-4, atol=2e-6, err_msg=k)
+
+
+def test_extrapolation_rank_and_offsets_match_reference_fixture():
+    """SURVEY 8 f4 host parts: segment_rank_fil (Temporal/extrapolation/segment.py:346-387) of the product against the output of the
+    reference's own function (tests/golden/extrap_rank.npz: ties, unreached targets, filters), and the vectorised
+    get_time_offset_list against the oracle's literal restatement of utils.py:692-699 (days without rows keep offset 0)."""
+    from red_gnn_amd import extrapolation as X
+    fx = U.load("extrap_rank.npz")
+    n_q = len(fx["target"])
+    sp2o = {(fx["sub"][q], fx["pre"][q]): fx["sp_idx"][fx["sp_ptr"][q]:fx["sp_ptr"][q + 1]] for q in range(n_q)}
+    spt2o = {(fx["sub"][q], fx["pre"][q], fx["ts"][q]): fx["spt_idx"][fx["spt_ptr"][q]:fx["spt_ptr"][q + 1]] for q in range(n_q)}
+    rank, found, rank_fil, rank_fil_t = X.segment_rank_fil(fx["scores"], fx["entities"], fx["target"], sp2o, spt2o, fx["sub"], fx["pre"], fx["ts"])
+    assert np.array_equal(rank, fx["rank"]) and np.array_equal(np.array(found), fx["found"])
+    assert np.array_equal(rank_fil, fx["rank_fil"]) and np.array_equal(rank_fil_t, fx["rank_fil_t"])
+    rng = np.random.default_rng(3)
+    days = np.sort(rng.choice(np.delete(np.arange(60), [0, 7, 8, 31]), 500))            # some days have no rows
+    data = np.stack([rng.integers(0, 9, 500), rng.integers(0, 3, 500), rng.integers(0, 9, 500), days * 24 + rng.integers(0, 24, 500)], 1)
+    data = data[np.argsort(data[:, 3], kind="stable")]
+    assert np.array_equal(X.get_time_offset_list(data, 24), orc.get_time_offset_list(data, 24))
