@@ -4,6 +4,7 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from red_gnn_amd.synthetic import SHAPES
 from red_gnn_amd.temporal import T_RED_GNN
+from red_gnn_amd.synthetic import make_temporal_shape
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 sh = SHAPES["C5"]
