@@ -34,6 +34,9 @@ typedef struct rg_frontier rg_frontier;  /* per-batch visited-set state inside a
 
 const char* rg_last_error(void);
 int rg_version(void);
+/* number of memset nodes in a captured hipGraph_t (-1 on error).  The library issues its fills as kernels because replayed graphs
+ * with several memset nodes misbehaved on ROCm 7.2; the host side asserts that nothing else put one into a captured forward. */
+int rg_hipgraph_fill_nodes(void* hip_graph);
 
 /* ---- graph build: replaces load_data.py:69-81 (double_triple + load_graph) ------------------
  * triples: HOST int32 [n,3] = (head, rel, tail) base triples.  If add_inverse != 0 the inverse

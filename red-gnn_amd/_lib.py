@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_PKG, "libredgnn.so")
 
 # every symbol include/redgnn.h declares (tests check the library exports all of them)
 SYMBOLS = [
-    "rg_last_error", "rg_version",
+    "rg_last_error", "rg_version", "rg_hipgraph_fill_nodes",
     "rg_graph_create", "rg_graph_create_device", "rg_graph_export_packs", "rg_tgraph_create", "rg_tgraph_create_excluding", "rg_graph_destroy", "rg_graph_n_fact", "rg_graph_export",
     "rg_frontier_workspace_bytes", "rg_frontier_create", "rg_frontier_destroy", "rg_frontier_reset",
     "rg_frontier_reset_nodes", "rg_frontier_expand", "rg_frontier_nodes", "rg_frontier_edges_scratch_bytes", "rg_frontier_edges",
@@ -42,6 +42,7 @@ def lib():
     vp, i32, i64, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_size_t
     L.rg_last_error.restype = C.c_char_p
     L.rg_version.restype = C.c_int
+    L.rg_hipgraph_fill_nodes.argtypes = [vp]
     L.rg_graph_create.argtypes = [i32, i32, vp, i64, C.c_int, C.POINTER(vp)]
     L.rg_graph_create_device.argtypes = [i32, i32, vp, i64, C.c_int, vp, C.POINTER(vp)]
     L.rg_graph_export_packs.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), vp, vp, vp, vp]

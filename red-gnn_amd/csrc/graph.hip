@@ -461,6 +461,22 @@ int rg_graph_export(const rg_graph* g, int32_t* out_ptr, int32_t* out_rt, int32_
   return 0;
 }
 
+// number of memset / memcpy nodes of a captured hipGraph (models._GraphedInference asserts 0: with ROCm 7.2 a replayed graph that holds
+// several memset nodes zeroed correctly on its first launch only, see common.h zero_async); -1 on error
+int rg_hipgraph_fill_nodes(void* graph) {
+  size_t n = 0;
+  if (hipGraphGetNodes((hipGraph_t)graph, nullptr, &n) != hipSuccess) { rg::set_error("rg_hipgraph_fill_nodes: hipGraphGetNodes failed"); return -1; }
+  std::vector<hipGraphNode_t> nodes(n);
+  if (n && hipGraphGetNodes((hipGraph_t)graph, nodes.data(), &n) != hipSuccess) { rg::set_error("rg_hipgraph_fill_nodes: hipGraphGetNodes failed"); return -1; }
+  int count = 0;
+  for (size_t i = 0; i < n; ++i) {
+    hipGraphNodeType t;
+    if (hipGraphNodeGetType(nodes[i], &t) != hipSuccess) { rg::set_error("rg_hipgraph_fill_nodes: hipGraphNodeGetType failed"); return -1; }
+    if (t == hipGraphNodeTypeMemset) ++count;
+  }
+  return count;
+}
+
 int rg_graph_export_packs(const rg_graph* g, int32_t* n_packs, int32_t* n_vrows, int32_t* ent, int32_t* pack, int32_t* rows, int32_t* vrows) {
   RG_CHECK(g != nullptr, "rg_graph_export_packs: graph is NULL");
   if (n_packs) *n_packs = g->in_pk_packs.n;

@@ -24,6 +24,9 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+import ctypes
+
+from . import _lib as _lib_mod
 from . import engine
 
 
@@ -250,9 +253,15 @@ class _GraphedInference:
         torch.cuda.current_stream(device).wait_stream(side)
         self.cuda_graph = None
         if os.environ.get("RG_NO_CAPTURE") != "1":           # debugging aid: enqueue the same sequence eagerly on every call
-            self.cuda_graph = torch.cuda.CUDAGraph()
+            self.cuda_graph = torch.cuda.CUDAGraph(keep_graph=True)
             with torch.cuda.graph(self.cuda_graph), torch.no_grad():
                 self._enqueue()
+            # every fill inside the forward is a kernel (common.h zero_async): a memset node here would mean a torch op started to
+            # emit one, and replays of graphs with several memset nodes zeroed correctly on their first launch only (ROCm 7.2)
+            n_fill = _lib_mod.lib().rg_hipgraph_fill_nodes(ctypes.c_void_p(self.cuda_graph.raw_cuda_graph()))
+            if n_fill != 0:
+                raise RuntimeError("captured forward holds %d memset nodes (expected none)" % n_fill)
+            self.cuda_graph.instantiate()
 
     @staticmethod
     def bytes_needed(n, n_ent, ld, ap):
