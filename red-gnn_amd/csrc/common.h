@@ -51,6 +51,10 @@ int scan_exclusive(const uint32_t* in, int32_t* out, int64_t n, bool popc, int32
 
 }  // namespace rg
 
+// best-fit placement of length-sorted virtual rows into packs (graph.hip; shared by the host and the device graph builders)
+#include <vector>
+namespace rg { int place_rows_best_fit(const int4* vrows, int32_t n_vrows, std::vector<int4>* place, std::vector<int32_t>* pack_nrows); }
+
 // ---- handles ----------------------------------------------------------------------------------
 // Virtual rows: the CSR rows of one direction cut into segments of at most RG_VROW_MAX entries and
 // sorted by length (descending).  Neighbouring work items then have similar trip counts (no idle

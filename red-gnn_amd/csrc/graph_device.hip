@@ -4,8 +4,8 @@
 // three CSRs (by tail in fact order; by head ordered by relation then fact order; by relation), packed entries, length-sorted
 // virtual rows and the word-parallel walk's packs are produced by stable radix sorts (hipCUB), scans and a few kernels; one
 // small read-back per CSR returns the counts that size the arena.  Every array equals the host builder's bit for bit (test:
-// test_device_graph_build_equals_host_build), including the packs: the best-fit packing is inherently sequential, so ONE
-// device thread runs the host's algorithm with its state in LDS (the triples and the CSR arrays never visit the host).
+// test_device_graph_build_equals_host_build), including the packs: their best-fit placement is inherently sequential, so the 16-byte
+// descriptors of the length-sorted rows (0.6 MB for 40 k rows) visit the host for it - the triples and the CSR arrays never do.
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
@@ -15,16 +15,26 @@
 
 namespace {
 
-struct Tmp {                      // temporaries of one build, freed at the end (also on error)
-  std::vector<void*> ptrs;
+struct Tmp {                      // temporaries of one build: slices of one device block (hipMalloc / hipFree synchronise and cost
+  std::vector<void*> ptrs;        // ~50 us each; sixty of them were half of the build), individual allocations beyond it
+  char* block = nullptr;
+  size_t block_bytes = 0, used = 0;
+  explicit Tmp(size_t bytes) {
+    if (hipMalloc((void**)&block, bytes) == hipSuccess) block_bytes = bytes; else block = nullptr;
+  }
   template <typename T>
   T* get(size_t n) {
+    const size_t bytes = rg::align_up(std::max<size_t>(n, 1) * sizeof(T), 256);
+    if (used + bytes <= block_bytes) { T* p = (T*)(block + used); used += bytes; return p; }
     void* p = nullptr;
-    if (hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
     ptrs.push_back(p);
     return (T*)p;
   }
-  ~Tmp() { for (void* p : ptrs) (void)hipFree(p); }
+  ~Tmp() {
+    for (void* p : ptrs) (void)hipFree(p);
+    if (block) (void)hipFree(block);
+  }
 };
 
 __global__ void rows_kernel(const int32_t* __restrict__ trip, int64_t n, int add_inverse, int n_ent, int n_rel, int max_rel,
@@ -108,86 +118,8 @@ __global__ void gather_rows_kernel(const uint32_t* __restrict__ perm, const int4
   if (i < n) out[i] = in[perm[i]];
 }
 
-// ---- packs (graph.hip host_packs): ONE thread runs the best-fit packing over the length-sorted rows -----------------------------
-// place[i] = {pack, first entry inside the pack, -, -}; *n_packs.  The packing state (fill level per pack, LIFO stacks of the open
-// packs per amount of room left) lives in LDS when it fits (<= 50 k virtual rows: one byte + one 16-bit link per pack), in global
-// memory otherwise; the non-empty room classes are a 129-bit mask in registers, so a row costs a few LDS round trips.
-template <typename FillT, typename LinkT>
-__device__ void pack_rows_seq(const int4* __restrict__ vrows, int n_vrows, int4* __restrict__ place, FillT* fill, LinkT* next, LinkT* head,
-                              int32_t* __restrict__ n_packs_out) {
-  constexpr LinkT NIL = (LinkT)~(LinkT)0;
-  for (int r = 0; r <= RG_PACK; ++r) head[r] = NIL;
-  unsigned long long open_lo = 0, open_hi = 0, open_top = 0;       // bit r of the 129-bit mask: some open pack has exactly r room
-  auto set_bit = [&](int r, bool on) {
-    unsigned long long& w = r < 64 ? open_lo : (r < 128 ? open_hi : open_top);
-    const unsigned long long m = 1ull << (r & 63);
-    w = on ? (w | m) : (w & ~m);
-  };
-  auto first_room_at_least = [&](int r) -> int {                   // smallest room >= r with an open pack, or RG_PACK + 1
-    if (r < 64) { const unsigned long long m = open_lo & (~0ull << r); if (m) return __ffsll((long long)m) - 1; r = 64; }
-    if (r < 128) { const unsigned long long m = open_hi & (~0ull << (r - 64)); if (m) return 64 + __ffsll((long long)m) - 1; }
-    return (open_top & 1ull) ? 128 : RG_PACK + 1;
-  };
-  int32_t n_packs = 0;
-  int4 r = n_vrows > 0 ? vrows[0] : make_int4(0, 0, 0, 0);
-  for (int i = 0; i < n_vrows; ++i) {
-    const int4 cur = r;
-    if (i + 1 < n_vrows) r = vrows[i + 1];                           // (independent of the packing state: in flight during this row)
-    if (cur.z <= 0) { place[i] = make_int4(-1, 0, 0, 0); continue; }
-    int p, off;
-    if (cur.w >= 0) {                          // a segment of a cut row keeps a pack to itself
-      p = n_packs++; off = 0; fill[p] = (FillT)cur.z;
-    } else {
-      int room = first_room_at_least(cur.z);
-      if (room > RG_PACK) { p = n_packs++; off = 0; room = RG_PACK; }
-      else {
-        p = (int)head[room]; off = (int)fill[p];
-        head[room] = next[p];
-        if (head[room] == NIL) set_bit(room, false);
-      }
-      fill[p] = (FillT)(off + cur.z);
-      const int left = room - cur.z;
-      if (left > 0) { next[p] = head[left]; head[left] = (LinkT)p; set_bit(left, true); }
-    }
-    place[i] = make_int4(p, off, 0, 0);
-  }
-  *n_packs_out = n_packs;
-}
-
-__global__ void pack_rows_lds_kernel(const int4* __restrict__ vrows, int n_vrows, int4* __restrict__ place, int32_t* __restrict__ n_packs_out) {
-  extern __shared__ unsigned char pack_lds[];
-  __shared__ unsigned short head[RG_PACK + 1];
-  if (threadIdx.x != 0) return;
-  unsigned short* next = reinterpret_cast<unsigned short*>(pack_lds);
-  unsigned char* fill = pack_lds + (size_t)n_vrows * 2;
-  pack_rows_seq<unsigned char, unsigned short>(vrows, n_vrows, place, fill, next, head, n_packs_out);
-}
-
-__global__ void pack_rows_global_kernel(const int4* __restrict__ vrows, int n_vrows, int4* __restrict__ place, int32_t* __restrict__ fill,
-                                        uint32_t* __restrict__ next, int32_t* __restrict__ n_packs_out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  uint32_t head[RG_PACK + 1];
-  pack_rows_seq<int32_t, uint32_t>(vrows, n_vrows, place, fill, next, head, n_packs_out);
-}
-
-// row index inside its pack = rank among the rows of the same pack in placement (= sorted row) order; rows per pack
-__global__ void pack_rank_kernel(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ sorted_pack, int n, int4* __restrict__ place,
-                                 int32_t* __restrict__ pack_nrows) {
-  const int q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= n) return;
-  const uint32_t p = sorted_pack[q];
-  if (p == 0xFFFFFFFFu) return;
-  int first = q;                              // rows of a pack are few (<= 128): walk back to the pack's first row
-  while (first > 0 && sorted_pack[first - 1] == p) --first;
-  place[perm[q]].z = q - first;
-  if (q + 1 == n || sorted_pack[q + 1] != p) pack_nrows[p] = q - first + 1;
-}
-
-__global__ void pack_keys_kernel(const int4* __restrict__ place, int n, uint32_t* __restrict__ keys) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) keys[i] = (uint32_t)place[i].x;      // -1 (empty row) sorts last
-}
-
+// ---- packs (graph.hip host_packs): the best-fit placement is sequential; the 16-byte descriptors of the length-sorted rows go to the
+// host for it (rg::place_rows_best_fit, the host builder's own routine) and the placements come back; entries are written here ---------
 __global__ void pack_emit_kernel(const int4* __restrict__ vrows, const int4* __restrict__ place, int n_vrows, const int32_t* __restrict__ pack_row0,
                                  const uint32_t* __restrict__ in_pk, int2* __restrict__ ent, int4* __restrict__ pack, int2* __restrict__ rows) {
   const int i = blockIdx.x;                  // one workgroup per virtual row
@@ -311,7 +243,7 @@ extern "C" int rg_graph_create_device(int32_t n_ent, int32_t n_rel, const int32_
   int rel_bits = 1, ent_bits = 1;
   while ((1 << rel_bits) < n_rela_rows) ++rel_bits;
   while (((int64_t)1 << ent_bits) < n_ent) ++ent_bits;
-  Tmp tmp;
+  Tmp tmp((size_t)n_fact * 160 + (size_t)n_ent * 96 + ((size_t)8 << 20));       // (rows, keys, permutations, CSRs, sort scratch, virtual rows)
   int32_t* H = tmp.get<int32_t>(n_fact); int32_t* R = tmp.get<int32_t>(n_fact); int32_t* T = tmp.get<int32_t>(n_fact);
   uint64_t* keys = tmp.get<uint64_t>(n_fact);
   uint32_t* perm_in = tmp.get<uint32_t>(n_fact); uint32_t* perm_out = tmp.get<uint32_t>(n_fact); uint32_t* perm_rel = tmp.get<uint32_t>(n_fact);
@@ -354,35 +286,18 @@ extern "C" int rg_graph_create_device(int32_t n_ent, int32_t n_rel, const int32_
   if (want_packs) {
     const int nv = host[0];
     place = tmp.get<int4>(nv);
-    int32_t* pack_fill = tmp.get<int32_t>(nv + 1);
     pack_nrows = tmp.get<int32_t>(nv + 1);
-    int32_t* next = tmp.get<int32_t>(nv + 1);
     pack_row0 = tmp.get<int32_t>(nv + 1);
     int32_t* scr = tmp.get<int32_t>(rg::scan_scratch_elems(nv + 1));
-    RG_CHECK(place && pack_fill && pack_nrows && next && pack_row0 && scr, "rg_graph_create_device: out of device memory");
-    if ((size_t)nv * 3 <= 150 * 1024) {
-      auto kern = pack_rows_lds_kernel;
-      if ((size_t)nv * 3 > 64 * 1024) DEV_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, nv * 3));
-      hipLaunchKernelGGL(kern, dim3(1), dim3(64), (size_t)nv * 3, s, vin.rows, nv, place, &flags[3]);
-    } else {
-      hipLaunchKernelGGL(pack_rows_global_kernel, dim3(1), dim3(64), 0, s, vin.rows, nv, place, pack_fill, (uint32_t*)next, &flags[3]);
-    }
-    DEV_HIP(hipMemcpyAsync(&n_packs, &flags[3], 4, hipMemcpyDeviceToHost, s));
+    RG_CHECK(place && pack_nrows && pack_row0 && scr, "rg_graph_create_device: out of device memory");
+    std::vector<int4> vrows_h(nv), place_h;
+    std::vector<int32_t> nrows_h;
+    DEV_HIP(hipMemcpyAsync(vrows_h.data(), vin.rows, (size_t)nv * sizeof(int4), hipMemcpyDeviceToHost, s));
     DEV_HIP(hipStreamSynchronize(s));
-    {   // ranks inside the packs: stable sort of the rows by pack id
-      uint32_t* pkeys = tmp.get<uint32_t>(nv); uint32_t* pkeys_o = tmp.get<uint32_t>(nv);
-      uint32_t* iota = tmp.get<uint32_t>(nv); uint32_t* pperm = tmp.get<uint32_t>(nv);
-      RG_CHECK(pkeys && pkeys_o && iota && pperm, "rg_graph_create_device: out of device memory");
-      hipLaunchKernelGGL(pack_keys_kernel, dim3(blocks(nv)), dim3(256), 0, s, place, nv, pkeys);
-      hipLaunchKernelGGL(iota_kernel, dim3(blocks(nv)), dim3(256), 0, s, iota, (int64_t)nv);
-      size_t bytes = 0;
-      DEV_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, pkeys, pkeys_o, iota, pperm, nv, 0, 32, s));
-      char* scratch = tmp.get<char>(bytes);
-      RG_CHECK(scratch != nullptr, "rg_graph_create_device: out of device memory");
-      DEV_HIP(hipcub::DeviceRadixSort::SortPairs(scratch, bytes, pkeys, pkeys_o, iota, pperm, nv, 0, 32, s));
-      DEV_HIP(hipMemsetAsync(pack_nrows, 0, (size_t)(nv + 1) * 4, s));
-      hipLaunchKernelGGL(pack_rank_kernel, dim3(blocks(nv)), dim3(256), 0, s, pperm, pkeys_o, nv, place, pack_nrows);
-    }
+    n_packs = rg::place_rows_best_fit(vrows_h.data(), nv, &place_h, &nrows_h);
+    DEV_HIP(hipMemcpyAsync(place, place_h.data(), (size_t)nv * sizeof(int4), hipMemcpyHostToDevice, s));
+    if (n_packs) DEV_HIP(hipMemcpyAsync(pack_nrows, nrows_h.data(), (size_t)n_packs * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    DEV_HIP(hipStreamSynchronize(s));          // (the host vectors go out of scope)
     if (rg::scan_exclusive((const uint32_t*)pack_nrows, pack_row0, n_packs, false, nullptr, scr, s)) return 1;
   }
   // ---- the arena: same slices as the host builder's ----------------------------------------------------------------------
