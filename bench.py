@@ -236,6 +236,9 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
+            # this image's RCCL prints a version banner on STDOUT at init (NCCL_DEBUG=VERSION behaviour); the contract is ONE JSON line there
+            if os.environ.get("NCCL_DEBUG", "").upper() in ("", "VERSION"):
+                os.environ["NCCL_DEBUG"] = "WARN"
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(args.backend)
