@@ -246,8 +246,9 @@ int rg_rank(const float* scores, int32_t batch, int32_t n_ent,
             float* ranks_out, void* stream);
 
 /* rg_dense_fwd with the node count read on the device (after rg_frontier_expand_async): n_cap = capacity of the row buffers,
- * n_dev = rg_frontier_count_ptr() of the frontier whose newest level the rows belong to. */
-int rg_dense_fwd_dev(int64_t n_cap, const int32_t* n_dev, int32_t d, int32_t ld, const float* agg, const float* hidden_prev,
+ * n_dev = rg_frontier_count_ptr() of the frontier whose newest level the rows belong to, n_hint = the row count the caller expects
+ * (0 = unknown): it only sizes the grid, every row count up to n_cap is processed correctly. */
+int rg_dense_fwd_dev(int64_t n_cap, const int32_t* n_dev, int64_t n_hint, int32_t d, int32_t ld, const float* agg, const float* hidden_prev,
                      const int32_t* prev_idx, const float* W_h, int32_t act,
                      const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
                      const float* Ws_next, int32_t attn_dim, int32_t ap, float* a_s_out,

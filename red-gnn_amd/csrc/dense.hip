@@ -52,15 +52,27 @@ __global__ __launch_bounds__(DENSE_T, 2) void dense_kernel(DenseArgs A) {
 
   const int d = A.d;
   // ---- weights -> LDS (zero padded, swizzled) ----------------------------------------------------------
+  // (one 16-B load per slot when the rows are 16-B aligned: the staging of the 7 images is the fixed cost of a launch, 10 of the 30 us
+  // a 50-query batch's launch takes)
+  const bool vec4 = (d & 3) == 0;
   auto load_w = [&](float4* dst, const float* src, int rows_src, int row0_dst, int rows_dst) {
+    const bool v4 = vec4 && ((uintptr_t)src & 15) == 0;
     for (int i = threadIdx.x; i < rows_dst * S; i += DENSE_T) {
       const int r = i / S, sl = i - r * S;
-      float v[4];
-      for (int k = 0; k < 4; ++k) {
-        const int c = sl * 4 + k;
-        v[k] = (src && r < rows_src && c < d) ? src[(int64_t)r * d + c] : 0.f;
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (src && r < rows_src) {
+        if (v4) {
+          if (sl * 4 < d) o = *reinterpret_cast<const float4*>(src + (int64_t)r * d + sl * 4);
+        } else {
+          float v[4];
+          for (int k = 0; k < 4; ++k) {
+            const int c = sl * 4 + k;
+            v[k] = c < d ? src[(int64_t)r * d + c] : 0.f;
+          }
+          o = make_float4(v[0], v[1], v[2], v[3]);
+        }
       }
-      dst[sw<DP>(row0_dst + r, sl)] = make_float4(v[0], v[1], v[2], v[3]);
+      dst[sw<DP>(row0_dst + r, sl)] = o;
     }
   };
   load_w(Wh_l, A.W_h, d, 0, DP);
@@ -306,7 +318,11 @@ int launch(const DenseArgs& A, hipStream_t s) {
   constexpr int DP = 16 * NB, S = DP / 4, NW = DENSE_T / 64;
   const size_t lds = (size_t)(7 * DP * S + 32 * S) * sizeof(float4) + 4 * DP * sizeof(float) + (size_t)NW * 16 * S * sizeof(float4);
   RG_HIP(hipFuncSetAttribute((const void*)dense_kernel<NB, TRAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const int grid = (int)std::min<int64_t>(rg::ceil_div(A.n_tiles, NW), 256);
+  // one persistent workgroup per CU at most; with a device-side row count the grid follows the caller's expectation (+25 %) instead of
+  // the capacity: a 50-query batch has a few hundred tiles, and 256 workgroups staging 123 KB of weights each kept every CU busy for
+  // 30 us per launch while other streams' batches waited
+  const int64_t tiles = A.n_dev && A.n_hint > 0 ? std::min<int64_t>(A.n_tiles, rg::ceil_div(A.n_hint + A.n_hint / 4, 16)) : A.n_tiles;
+  const int grid = (int)std::max<int64_t>(std::min<int64_t>(rg::ceil_div(tiles, NW), 256), 1);
   hipLaunchKernelGGL((dense_kernel<NB, TRAIN>), dim3(grid), dim3(DENSE_T), lds, s, A);
   RG_LAUNCH_CHECK();
   return 0;
@@ -316,7 +332,7 @@ int launch(const DenseArgs& A, hipStream_t s) {
 
 extern "C" int rg_dense_fwd_supported(int32_t d, int32_t attn_dim) { return ((d >= 1 && d <= 64) || d == 128) && attn_dim <= 16; }
 
-static int dense_fwd_impl(int64_t n, const int32_t* n_dev, int32_t d, int32_t ld, const float* agg, const float* hidden_prev,
+static int dense_fwd_impl(int64_t n, const int32_t* n_dev, int64_t n_hint, int32_t d, int32_t ld, const float* agg, const float* hidden_prev,
                           const int32_t* prev_idx, const float* W_h, int32_t act, const float* w_ih, const float* w_hh,
                           const float* b_ih, const float* b_hh, const float* Ws_next, int32_t attn_dim, int32_t ap,
                           float* a_s_out, const float* W_final, const int32_t* nodes, int32_t n_ent, float* scores_all,
@@ -333,7 +349,7 @@ static int dense_fwd_impl(int64_t n, const int32_t* n_dev, int32_t d, int32_t ld
            "rg_dense_fwd: float buffers must be 16-B aligned");
   if (n == 0) return 0;
   DenseArgs A;
-  A.n = n; A.n_dev = n_dev; A.d = d; A.ld4 = ld / 4;
+  A.n = n; A.n_dev = n_dev; A.n_hint = n_hint; A.d = d; A.ld4 = ld / 4;
   A.agg = (const float4*)agg; A.hprev = (const float4*)hidden_prev; A.prev_idx = prev_idx;
   A.W_h = W_h; A.w_ih = w_ih; A.w_hh = w_hh; A.b_ih = b_ih; A.b_hh = b_hh;
   A.Ws = Ws_next; A.attn = attn_dim; A.ap = ap; A.a_s_out = a_s_out;
@@ -350,17 +366,17 @@ extern "C" int rg_dense_fwd(int64_t n, int32_t d, int32_t ld, const float* agg, 
                             const float* b_ih, const float* b_hh, const float* Ws_next, int32_t attn_dim, int32_t ap,
                             float* a_s_out, const float* W_final, const int32_t* nodes, int32_t n_ent, float* scores_all,
                             float* hidden_out, void* stream) {
-  return dense_fwd_impl(n, nullptr, d, ld, agg, hidden_prev, prev_idx, W_h, act, w_ih, w_hh, b_ih, b_hh, Ws_next, attn_dim, ap,
+  return dense_fwd_impl(n, nullptr, 0, d, ld, agg, hidden_prev, prev_idx, W_h, act, w_ih, w_hh, b_ih, b_hh, Ws_next, attn_dim, ap,
                         a_s_out, W_final, nodes, n_ent, scores_all, hidden_out, stream);
 }
 
-extern "C" int rg_dense_fwd_dev(int64_t n_cap, const int32_t* n_dev, int32_t d, int32_t ld, const float* agg,
+extern "C" int rg_dense_fwd_dev(int64_t n_cap, const int32_t* n_dev, int64_t n_hint, int32_t d, int32_t ld, const float* agg,
                                 const float* hidden_prev, const int32_t* prev_idx, const float* W_h, int32_t act,
                                 const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, const float* Ws_next,
                                 int32_t attn_dim, int32_t ap, float* a_s_out, const float* W_final, const int32_t* nodes,
                                 int32_t n_ent, float* scores_all, float* hidden_out, void* stream) {
   RG_CHECK(n_dev != nullptr, "rg_dense_fwd_dev: n_dev is NULL");
-  return dense_fwd_impl(n_cap, n_dev, d, ld, agg, hidden_prev, prev_idx, W_h, act, w_ih, w_hh, b_ih, b_hh, Ws_next, attn_dim, ap,
+  return dense_fwd_impl(n_cap, n_dev, n_hint, d, ld, agg, hidden_prev, prev_idx, W_h, act, w_ih, w_hh, b_ih, b_hh, Ws_next, attn_dim, ap,
                         a_s_out, W_final, nodes, n_ent, scores_all, hidden_out, stream);
 }
 

@@ -304,7 +304,8 @@ int dense128_launch(const DenseArgs& A, hipStream_t s) {
   const size_t lds = (size_t)(2 * CHUNK + 32 * S + NW * 16 * S) * sizeof(float4) + 4 * DP * sizeof(float);
   auto kern = A.ws_out ? dense128_kernel<true> : dense128_kernel<false>;
   RG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const int grid = (int)std::min<int64_t>(ceil_div(A.n_tiles, NW), 256);
+  const int64_t tiles = A.n_dev && A.n_hint > 0 ? std::min<int64_t>(A.n_tiles, ceil_div(A.n_hint + A.n_hint / 4, 16)) : A.n_tiles;
+  const int grid = (int)std::max<int64_t>(std::min<int64_t>(ceil_div(tiles, NW), 256), 1);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(T), lds, s, A);
   RG_LAUNCH_CHECK();
   return 0;

@@ -29,6 +29,7 @@ struct DenseArgs {
   float4* hidden_out;      // [n][ld4]
   int act;                 // 0 idd, 1 relu, 2 tanh
   int n_tiles;
+  int64_t n_hint = 0;      // host side: expected number of rows when n is only a capacity (sizes the grid; any value is correct)
   // training variant (rg_dense_train_fwd): dropout mask in, GRU input and gate workspace out
   const float* mask = nullptr;   // [n][ld] 0 or 1/(1-p), or null
   float* x_out = nullptr;        // [n][ld]  act(W_h agg) * mask

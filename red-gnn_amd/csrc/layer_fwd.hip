@@ -57,6 +57,8 @@ extern "C" int rg_layer_fwd(const rg_frontier* f, const rg_graph* g, int32_t lev
   if (walk == 0)      // sizes known on the host (after rg_frontier_expand): pick; after expand_async the caller says which
     walk = plan_walk(f, g, level, f->n_nodes[(level - 1) % f->n_levels], f->n_nodes[level % f->n_levels],
                      level == f->level ? f->n_edges : -1, ld);
+  if (walk >= 2 && f->n_nodes[(level - 1) % f->n_levels] < 0 && !rgwp::offsets_fit((int64_t)f->B * f->n_ent, ld))
+    walk = 1;       // sizes unknown on the host (expand_async) and the full grid would overflow the 32-bit row offsets: per-query walk
   if (walk >= 2) {
     RG_CHECK(g->in_pk_packs.n > 0, "rg_layer_fwd: the word-parallel walk needs a static graph with packed entries");
     RG_CHECK(level == f->level, "rg_layer_fwd: the word-parallel walk reads the entity-major bitmaps of the newest hop only "

@@ -279,7 +279,7 @@ class FrontierLease:
 class FrontierPool:
     """Frontiers per shape key; ``get`` returns one that no live autograd graph leases (allocating another if needed)."""
 
-    def __init__(self, max_keys=8):
+    def __init__(self, max_keys=64):      # (8 evaluation lanes x a few batch shapes)
         self.max_keys, self.pool = max_keys, {}
 
     def get(self, n_ent, batch, n_levels, device):
@@ -472,13 +472,13 @@ def dense_fwd(agg, hidden_prev, prev_idx, d, W_h, act, gate, Ws_next=None, attn_
 
 
 def dense_fwd_dev(n_cap, count_ptr, agg, hidden_prev, prev_idx, d, W_h, act, gate, hidden_out, Ws_next=None, attn_dim=0, ap=0,
-                  a_s_out=None, W_final=None, nodes=None, n_ent=0, scores_all=None):
+                  a_s_out=None, W_final=None, nodes=None, n_ent=0, scores_all=None, n_hint=0):
     """rg_dense_fwd_dev: the fused dense epilogue with the row count read on the device (buffers of capacity n_cap)."""
     ld = agg.shape[1]
     c = lambda t: None if t is None else t.detach().contiguous()
     W_h, w_ih, w_hh, b_ih, b_hh = c(W_h), c(gate.weight_ih_l0), c(gate.weight_hh_l0), c(gate.bias_ih_l0), c(gate.bias_hh_l0)
     Ws_next, W_final = c(Ws_next), c(W_final)
-    _lib.check(_lib.lib().rg_dense_fwd_dev(n_cap, count_ptr, d, ld, _lib.ptr(agg), _lib.ptr(hidden_prev), _lib.ptr(prev_idx),
+    _lib.check(_lib.lib().rg_dense_fwd_dev(n_cap, count_ptr, int(n_hint), d, ld, _lib.ptr(agg), _lib.ptr(hidden_prev), _lib.ptr(prev_idx),
                                            _lib.ptr(W_h), {"idd": 0, "relu": 1, "tanh": 2}[act], _lib.ptr(w_ih), _lib.ptr(w_hh),
                                            _lib.ptr(b_ih), _lib.ptr(b_hh), _lib.ptr(Ws_next), attn_dim, ap, _lib.ptr(a_s_out),
                                            _lib.ptr(W_final), _lib.ptr(nodes), n_ent, _lib.ptr(scores_all), _lib.ptr(hidden_out),

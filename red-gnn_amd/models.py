@@ -287,7 +287,7 @@ class _GraphedInference:
             engine.dense_fwd_dev(self.cap, fr.count_ptr(), self.agg, hidden, self.prev, d, layer.W_h.weight, m.act_name, m.gate, out_h,
                                  Ws_next=None if last else m.gnn_layers[i + 1].Ws_attn.weight, attn_dim=a, ap=ap,
                                  a_s_out=None if last else out_a, W_final=m.W_final.weight if last else None,
-                                 nodes=self.nodes, n_ent=graph.n_ent, scores_all=self.scores)
+                                 nodes=self.nodes, n_ent=graph.n_ent, scores_all=self.scores, n_hint=n_hint)
             hidden, a_s = out_h, out_a
 
     def run(self, q_sub, q_rel):

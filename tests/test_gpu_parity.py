@@ -1114,6 +1114,11 @@ def test_dense_kernel_row_count_edges(d, n):
         h_ref, as_ref, _ = reference(prev)
         np.testing.assert_allclose(out[:n].cpu().numpy(), h_ref.cpu().numpy(), rtol=RTOL, atol=ATOL_H)
         assert bool((out[n:] == -7.0).all()) and bool((a_out[n:] == -7.0).all())
+        # n_hint only sizes the grid: far too small an expectation still processes every row
+        out2 = torch.full((cap, d), -7.0, device=dev)
+        engine.dense_fwd_dev(cap, ctypes.c_void_p(count.data_ptr()), agg_c, hprev, prev_c, d, W_h, "tanh", gate, out2, Ws_next=Ws, attn_dim=a,
+                             ap=ap, a_s_out=a_out, n_hint=max(1, n // 7))
+        assert torch.equal(out2, out)
 
 
 def test_graph_replay_inductive_switches_graphs():
