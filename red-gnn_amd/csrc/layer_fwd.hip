@@ -42,9 +42,7 @@ extern "C" int rg_layer_fwd(const rg_frontier* f, const rg_graph* g, int32_t lev
   RG_CHECK(f && g && hidden && rela && a_s && a_r && a_q && w_alpha && b_alpha && agg_out, "rg_layer_fwd: NULL argument");
   RG_CHECK((((uintptr_t)hidden | (uintptr_t)rela | (uintptr_t)a_s | (uintptr_t)a_r | (uintptr_t)a_q | (uintptr_t)agg_out |
              (uintptr_t)scratch) & 15) == 0, "rg_layer_fwd: float buffers must be 16-B aligned");
-  const int variant = walk >> 4;      // (tuning aid: bits 4-5 pick a lane grouping of the word-parallel kernel; 0 = default)
-  walk &= 15;
-  RG_CHECK(walk >= 0 && walk <= 4 && variant <= 2, "rg_layer_fwd: walk=%d not in 0..4", walk);
+  RG_CHECK(walk >= 0 && walk <= 4, "rg_layer_fwd: walk=%d not in 0..4", walk);
   rgfwd::FwdArgs A;
   if (rgfwd::fill_common("rg_layer_fwd", f, g, level, n_new, d, ld, ap, attn_dim, scratch, scratch_bytes,
                          rg_layer_fwd_scratch_bytes(f, g, ld), &A)) return 1;
@@ -84,7 +82,7 @@ extern "C" int rg_layer_fwd(const rg_frontier* f, const rg_graph* g, int32_t lev
     const size_t n_part = (size_t)f->B * g->in_vr.n_slots;
     W.written = n_part ? (uint8_t*)scratch + rg::align_up(n_part * ld * sizeof(float), 256) : nullptr;
     if (n_part && rg::zero_async(W.written, rg::align_up(n_part, 256), s)) return 1;
-    if (rgwp::launch(W, ap / 4, variant, s)) return 1;
+    if (rgwp::launch(W, ap / 4, s)) return 1;
     return rgfwd::launch_combine(A, f->B, g->in_vr, s, W.written);
   }
   // dense walk when at least a quarter of all (query, entity) pairs are visited; else filter 64 items per wave

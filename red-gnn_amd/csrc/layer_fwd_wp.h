@@ -34,7 +34,7 @@ struct WpArgs {
 };
 
 // launches the kernel (and nothing else: the caller runs combine_kernel for cut rows, as after the per-query walk)
-int launch(const WpArgs& A, int ap4, int variant, hipStream_t s);   // variant: lane grouping to try (0 = the default for the width)
+int launch(const WpArgs& A, int ap4, hipStream_t s);
 // the kernel addresses the previous level's rows by 32-bit byte offsets: n_old * ld * 4 must stay below 4 GiB
 bool offsets_fit(int64_t n_old, int32_t ld);
 

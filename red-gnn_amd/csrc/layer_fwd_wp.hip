@@ -351,20 +351,15 @@ int launch_ap(const WpArgs& A, int ap4, hipStream_t s) {
 
 bool offsets_fit(int64_t n_old, int32_t ld) { return n_old >= 0 && (uint64_t)n_old * ld * sizeof(float) < ((uint64_t)1 << 32); }
 
-int launch(const WpArgs& A, int ap4, int variant, hipStream_t s) {
+// lane grouping per row width: two float4 per lane (one 128-byte line per group and load instruction at d = 64).  Measured on C2's
+// second hop: (16 lanes, 1 float4) 1.79 ms, (8, 2) 1.75 ms, (4, 4) 2.12 ms (twice the L1 transactions per row, 16-way conflicts on
+// the tuple reads) - profiles/r02/per_hop_wp_lane_grouping_variants.txt
+int launch(const WpArgs& A, int ap4, hipStream_t s) {
   RG_CHECK(A.n_items / 8 + ((int64_t)1 << 26) < ((int64_t)1 << 31), "rg_layer_fwd: work space too large for 32-bit queue tickets");
   if (A.ld4 <= 4) return launch_ap<2, 2>(A, ap4, s);
   if (A.ld4 <= 8) return launch_ap<4, 2>(A, ap4, s);
-  if (A.ld4 <= 16) {
-    if (variant == 1) return launch_ap<4, 4>(A, ap4, s);
-    if (variant == 2) return launch_ap<16, 1>(A, ap4, s);
-    return launch_ap<8, 2>(A, ap4, s);
-  }
-  if (A.ld4 <= 32) {
-    if (variant == 1) return launch_ap<8, 4>(A, ap4, s);
-    if (variant == 2) return launch_ap<32, 1>(A, ap4, s);
-    return launch_ap<16, 2>(A, ap4, s);
-  }
+  if (A.ld4 <= 16) return launch_ap<8, 2>(A, ap4, s);
+  if (A.ld4 <= 32) return launch_ap<16, 2>(A, ap4, s);
   return launch_ap<32, 2>(A, ap4, s);
 }
 
