@@ -9,7 +9,7 @@ extern "C" size_t rg_layer_fwd_scratch_bytes(const rg_frontier* f, const rg_grap
   return rg::align_up((size_t)f->B * g->in_vr.n_slots * ld * sizeof(float), 256) + rg::align_up((size_t)f->B * g->in_vr.n_slots, 256) + 256;
 }
 
-// walk codes: 1 = per-query walk; 2, 3, 4 = word-parallel with 32, 16, 8 queries per item
+// walk codes: 1 = per-query walk; 2, 3, 4, 5 = word-parallel with 32, 16, 8, 4 queries per item
 static int plan_walk(const rg_frontier* f, const rg_graph* g, int32_t level, int64_t n_old, int64_t n_new, int64_t n_edges, int32_t ld) {
   if (g->in_pk_packs.n == 0 || level != f->level || n_old < 0 || n_new <= 0 || n_edges < 0 || !rgwp::offsets_fit(n_old, ld)) return 1;
   // per-query walk: tests every in-edge of every live destination (~ n_new * mean in-degree candidates) after testing all
@@ -25,7 +25,9 @@ static int plan_walk(const rg_frontier* f, const rg_graph* g, int32_t level, int
   int code = group_bytes <= 3.0 * (1 << 20) ? 2 : (group_bytes <= 6.0 * (1 << 20) ? 3 : 4);
   // small batches: fewer items than the chip has wave slots -> the launch lasts as long as its heaviest item; smaller query groups
   // (more, lighter items) shorten that critical path (family, 50 queries: 800 items of ~170 edges -> 3200 of ~43)
-  while (code < 4 && (int64_t)f->BW * (1 << (code - 2)) * g->in_pk_packs.n < 8192) ++code;
+  // (only while an item still carries a few hundred edges: lighter items cost more in tickets and fixed per-item work than they balance)
+  auto items = [&](int c) { return (int64_t)f->BW * (1 << (c - 2)) * g->in_pk_packs.n; };
+  while (code < 5 && items(code) < 16384 && n_edges > 256 * items(code)) ++code;
   return code;
 }
 
@@ -42,7 +44,7 @@ extern "C" int rg_layer_fwd(const rg_frontier* f, const rg_graph* g, int32_t lev
   RG_CHECK(f && g && hidden && rela && a_s && a_r && a_q && w_alpha && b_alpha && agg_out, "rg_layer_fwd: NULL argument");
   RG_CHECK((((uintptr_t)hidden | (uintptr_t)rela | (uintptr_t)a_s | (uintptr_t)a_r | (uintptr_t)a_q | (uintptr_t)agg_out |
              (uintptr_t)scratch) & 15) == 0, "rg_layer_fwd: float buffers must be 16-B aligned");
-  RG_CHECK(walk >= 0 && walk <= 4, "rg_layer_fwd: walk=%d not in 0..4", walk);
+  RG_CHECK(walk >= 0 && walk <= 5, "rg_layer_fwd: walk=%d not in 0..5", walk);
   rgfwd::FwdArgs A;
   if (rgfwd::fill_common("rg_layer_fwd", f, g, level, n_new, d, ld, ap, attn_dim, scratch, scratch_bytes,
                          rg_layer_fwd_scratch_bytes(f, g, ld), &A)) return 1;
