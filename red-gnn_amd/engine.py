@@ -11,7 +11,7 @@ import torch
 from . import _lib
 
 
-# tests set this to 1 (per-query walk) or 2..4 (word-parallel, 32/16/8 queries per item) to force rg_layer_fwd's edge walk; 0 = the
+# tests set this to 1 (per-query walk) or 2..5 (word-parallel, 32/16/8/4 queries per item) to force rg_layer_fwd's edge walk; 0 = the
 # library picks from the hop's sizes
 FORCE_WALK = 0
 
