@@ -959,6 +959,36 @@ def test_random_graphs_fuzz_vs_oracle():
             assert len(model._graphed) == 1 and np.array_equal(s3.cpu().numpy(), s), case
 
 
+def test_evaluation_lanes_give_the_same_metrics():
+    """BaseModel.evaluate deals batches to EVAL_LANES streams (each replaying its own captured forward): ranks - and so MRR / H@k -
+    are identical to the single-stream evaluation, pass after pass (eager warm-up calls, captures and replays included)."""
+    from red_gnn_amd.base_model import BaseModel
+    from red_gnn_amd.load_data import DataLoader
+    ids = U.load("family_ids.npz")
+    loader = DataLoader(ids=ids, verbose=False)
+
+    class Opt:
+        lr, decay_rate, lamb, hidden_dim, attn_dim, n_layer, dropout, act, n_batch, n_tbatch = 0.0036, 0.999, 1.7e-5, 32, 5, 3, 0.1, "relu", 20, 50
+        n_rel = loader.n_rel
+
+    torch.manual_seed(7)
+    bm = BaseModel(Opt, loader)
+    bm.n_valid, bm.n_test = 620, 415                      # 13 + 9 batches, both with a partial last batch
+    bm.model.eval()
+    saved = BaseModel.EVAL_LANES
+    try:
+        BaseModel.EVAL_LANES = 1
+        ref_v = bm._rank_split("valid", bm.n_valid).cpu().numpy()
+        ref_t = bm._rank_split("test", bm.n_test).cpu().numpy()
+        BaseModel.EVAL_LANES = 8
+        for _ in range(4):                                  # warm-up (eager), capture, replays
+            assert np.array_equal(bm._rank_split("valid", bm.n_valid).cpu().numpy(), ref_v)
+            assert np.array_equal(bm._rank_split("test", bm.n_test).cpu().numpy(), ref_t)
+    finally:
+        BaseModel.EVAL_LANES = saved
+    assert len(bm.model._graphed) >= 8
+
+
 def test_inductive_training_learns():
     """The reference's loop in the inductive setting (train on the transductive graph's valid triples, evaluate the
     'test' split on the inductive graph with its own entity set): one short epoch lifts the inductive MRR."""

@@ -283,3 +283,11 @@ def test_loader_id_cache_roundtrip():
         for i, (h, r) in enumerate(c.test_q):
             assert list(fidx[fptr[i]:fptr[i + 1]]) == c.filters[(h, r)]
         assert x.filters == c.filters                               # ... and the dict is rebuilt when asked for
+
+
+def test_attention_width_padding():
+    """Kernel attention widths: multiples of 4 up to 16, then 32; wider is refused with a clear error (the reference accepts any)."""
+    from red_gnn_amd.models import pad_attn
+    assert [pad_attn(a) for a in (1, 3, 4, 5, 10, 16, 17, 28, 30, 32)] == [4, 4, 4, 8, 12, 16, 32, 32, 32, 32]
+    with pytest.raises(ValueError):
+        pad_attn(33)
