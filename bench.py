@@ -210,6 +210,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=1024, help="queries per GPU per step")
     ap.add_argument("--config", default="C2")
+    ap.add_argument("--dense-precision", default=None, choices=["f32", "f16x2"],
+                    help="matrix products of the fused dense kernel (default: the model's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-family-eval", action="store_true", help="skip BaseModel.evaluate on the real family graph (runs after the timed region "
@@ -256,6 +258,8 @@ def main():
     loader = DataLoader(ids=ids, verbose=False)
     torch.manual_seed(1234)
     model = RED_GNN_trans(Params(shape, kg.n_rel), loader).cuda().eval()
+    if args.dense_precision:
+        model.dense_precision = args.dense_precision
     model.use_graphs = args.graphs            # the default run keeps the eager path: its kernels are timed one by one below
     d = shape["hidden_dim"]
 

@@ -85,8 +85,8 @@ def lib():
     L.rg_tlayer_bwd.argtypes = [vp, vp, i32, i64, vp, vp, vp, vp, i32, i32, vp, vp, vp, i32, vp, vp, i32,
                                 vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
     L.rg_dense_fwd_supported.argtypes = [i32, i32]
-    L.rg_dense_fwd.argtypes = [i64, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, i32, vp, vp, vp]
-    L.rg_dense_fwd_dev.argtypes = [i64, vp, i64, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, i32, vp, vp, vp]
+    L.rg_dense_fwd.argtypes = [i64, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, i32, vp, vp, i32, vp]
+    L.rg_dense_fwd_dev.argtypes = [i64, vp, i64, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, i32, vp, vp, i32, vp]
     L.rg_dense_train_fwd.argtypes = [i64, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.rg_dense_train_bwd.argtypes = [i64, i32, vp, vp, vp, vp, C.c_float, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.rg_rank.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp]

@@ -46,5 +46,7 @@ static __device__ __forceinline__ float fast_tanh(float x) {
 
 // d = 128 (dense128.hip)
 int dense128_launch(const DenseArgs& A, hipStream_t s);
+// d <= 64 with the products as two-term f16 splits (dense_split.hip)
+int dense_split_launch(const DenseArgs& A, hipStream_t s);
 
 }  // namespace rg

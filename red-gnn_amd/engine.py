@@ -447,9 +447,13 @@ def dense_supported(d, attn_dim):
     return bool(_lib.lib().rg_dense_fwd_supported(d, attn_dim))
 
 
+DENSE_PRECISIONS = {"f32": 0, "f16x2": 1}
+
+
 def dense_fwd(agg, hidden_prev, prev_idx, d, W_h, act, gate, Ws_next=None, attn_dim=0, ap=0, W_final=None, nodes=None,
-              n_ent=0, scores_all=None):
-    """Fused W_h + act + GRU step (+ next layer's a_s, + readout) on f32 MFMA (rg_dense_fwd).
+              n_ent=0, scores_all=None, precision="f32"):
+    """Fused W_h + act + GRU step (+ next layer's a_s, + readout) on the matrix cores (rg_dense_fwd).  precision: "f32" = exact
+    fp32 MFMA, "f16x2" = two-term f16 splits of every operand (22 bits, fp32 accumulation; see include/redgnn.h).
     Returns (hidden_new [n, ld], a_s_next [n, ap] or None)."""
     n, ld = agg.shape
     hidden = torch.empty_like(agg)
@@ -464,7 +468,8 @@ def dense_fwd(agg, hidden_prev, prev_idx, d, W_h, act, gate, Ws_next=None, attn_
     _lib.check(_lib.lib().rg_dense_fwd(n, d, ld, _lib.ptr(agg), _lib.ptr(hidden_prev), _lib.ptr(prev_idx), _lib.ptr(W_h),
                                        {"idd": 0, "relu": 1, "tanh": 2}[act], _lib.ptr(w_ih), _lib.ptr(w_hh), _lib.ptr(b_ih),
                                        _lib.ptr(b_hh), _lib.ptr(Ws_next), attn_dim, ap, _lib.ptr(a_s), _lib.ptr(W_final),
-                                       _lib.ptr(nodes), n_ent, _lib.ptr(scores_all), _lib.ptr(hidden), _lib.stream_ptr()))
+                                       _lib.ptr(nodes), n_ent, _lib.ptr(scores_all), _lib.ptr(hidden), DENSE_PRECISIONS[precision],
+                                       _lib.stream_ptr()))
     if ev is not None:
         ev[1].record()
         DENSE_EVENTS.append((ev[0], ev[1], n))
@@ -472,7 +477,7 @@ def dense_fwd(agg, hidden_prev, prev_idx, d, W_h, act, gate, Ws_next=None, attn_
 
 
 def dense_fwd_dev(n_cap, count_ptr, agg, hidden_prev, prev_idx, d, W_h, act, gate, hidden_out, Ws_next=None, attn_dim=0, ap=0,
-                  a_s_out=None, W_final=None, nodes=None, n_ent=0, scores_all=None, n_hint=0):
+                  a_s_out=None, W_final=None, nodes=None, n_ent=0, scores_all=None, n_hint=0, precision="f32"):
     """rg_dense_fwd_dev: the fused dense epilogue with the row count read on the device (buffers of capacity n_cap)."""
     ld = agg.shape[1]
     c = lambda t: None if t is None else t.detach().contiguous()
@@ -482,7 +487,7 @@ def dense_fwd_dev(n_cap, count_ptr, agg, hidden_prev, prev_idx, d, W_h, act, gat
                                            _lib.ptr(W_h), {"idd": 0, "relu": 1, "tanh": 2}[act], _lib.ptr(w_ih), _lib.ptr(w_hh),
                                            _lib.ptr(b_ih), _lib.ptr(b_hh), _lib.ptr(Ws_next), attn_dim, ap, _lib.ptr(a_s_out),
                                            _lib.ptr(W_final), _lib.ptr(nodes), n_ent, _lib.ptr(scores_all), _lib.ptr(hidden_out),
-                                           _lib.stream_ptr()))
+                                           DENSE_PRECISIONS[precision], _lib.stream_ptr()))
 
 
 def dense_train_supported(d, act):

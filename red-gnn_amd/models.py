@@ -287,7 +287,7 @@ class _GraphedInference:
             engine.dense_fwd_dev(self.cap, fr.count_ptr(), self.agg, hidden, self.prev, d, layer.W_h.weight, m.act_name, m.gate, out_h,
                                  Ws_next=None if last else m.gnn_layers[i + 1].Ws_attn.weight, attn_dim=a, ap=ap,
                                  a_s_out=None if last else out_a, W_final=m.W_final.weight if last else None,
-                                 nodes=self.nodes, n_ent=graph.n_ent, scores_all=self.scores, n_hint=n_hint)
+                                 nodes=self.nodes, n_ent=graph.n_ent, scores_all=self.scores, n_hint=n_hint, precision=m.dense_precision)
             hidden, a_s = out_h, out_a
 
     def run(self, q_sub, q_rel):
@@ -320,6 +320,7 @@ class RED_GNN_trans(nn.Module):
         self._frontiers = engine.FrontierPool()
         self._last_stats = None
         self.fused_dense = True      # inference: W_h + GRU + projections + readout in one MFMA kernel (rg_dense_fwd)
+        self.dense_precision = "f32"   # matrix products of that kernel: "f32" (exact fp32 MFMA) or "f16x2" (two-term f16 splits)
         self.use_graphs = True       # inference: replay a captured HIP graph per (graph, batch size) from the third call on
         self._graphed, self._seen, self._hints, self._pending_key, self._graph_failed = {}, {}, {}, None, set()
 
@@ -414,7 +415,7 @@ class RED_GNN_trans(nn.Module):
         Returns None when this call should run eagerly: the first two calls of a shape (the eager run also provides the
         per-hop sizes that pick the kernels' walks), or shapes whose full-grid buffers would be too large."""
         # one captured graph (with its own full-grid buffers) per stream: the evaluator's lanes replay concurrently
-        key = (id(graph), n, str(device), torch.cuda.current_stream(device).cuda_stream)
+        key = (id(graph), n, str(device), torch.cuda.current_stream(device).cuda_stream, self.dense_precision)
         g = self._graphed.get(key)
         if g is not None and g.key_ptr != self.W_final.weight.data_ptr():        # parameters were re-allocated (.to(), ...)
             g = None
@@ -471,7 +472,8 @@ class RED_GNN_trans(nn.Module):
             hidden, a_s = engine.dense_fwd(
                 agg, hidden, prev_idx, d, layer.W_h.weight, self.act_name, self.gate,
                 Ws_next=None if last else self.gnn_layers[i + 1].Ws_attn.weight, attn_dim=a, ap=ap,
-                W_final=self.W_final.weight if last else None, nodes=nodes, n_ent=n_ent, scores_all=scores_all)
+                W_final=self.W_final.weight if last else None, nodes=nodes, n_ent=n_ent, scores_all=scores_all,
+                precision=self.dense_precision)
             if trace is not None:
                 trace.append(dict(nodes=nodes, old_nodes_new_idx=old_new, n_edges=n_e, hidden=hidden[:, :d]))
         self.last_stats = dict(n_edges=n_edges, n_nodes=int(nodes.shape[0]))

@@ -501,16 +501,20 @@ def test_full_size_properties_c2():
         prev = nodes
 
 
+@pytest.mark.parametrize("prec", ["f32", "f16x2"])
 @pytest.mark.parametrize("d,a,act", [(64, 5, "relu"), (48, 5, "tanh"), (32, 3, "idd"), (20, 10, "relu"), (30, 16, "tanh"), (128, 5, "relu")])
-def test_fused_dense_kernel_matches_torch_dense_path(d, a, act):
-    """rg_dense_fwd (f32 MFMA: W_h + act + GRU + next a_s + readout) against the same model with the
-    dense part in torch ops (rocBLAS + gru_cell): same nodes, hidden and scores."""
+def test_fused_dense_kernel_matches_torch_dense_path(d, a, act, prec):
+    """rg_dense_fwd (W_h + act + GRU + next a_s + readout on the matrix cores, as exact fp32 MFMA and as two-term f16 splits)
+    against the same model with the dense part in torch ops (rocBLAS + gru_cell): same nodes, hidden and scores."""
+    if d == 128 and prec == "f16x2":
+        pytest.skip("d = 128 has one kernel for both settings")
     from red_gnn_amd.load_data import DataLoader
     from red_gnn_amd.synthetic import make_synthetic_kg
     kg = make_synthetic_kg(700, 9, 9000, seed=21)
     ids = dict(n_ent=kg.n_ent, n_rel=kg.n_rel, facts=kg.facts, train=kg.train, valid=kg.valid, test=kg.test)
     loader = DataLoader(ids=ids, verbose=False)
     model = _random_model(loader, 3, d, a, act, seed=7)
+    model.dense_precision = prec
     rng = np.random.default_rng(1)
     subs, rels = rng.integers(0, kg.n_ent, 37), rng.integers(0, 2 * kg.n_rel, 37)
     t1, t2 = [], []
@@ -1092,9 +1096,9 @@ def test_graph_replay_matches_eager_forward():
     assert len(model._graphed) == 1
 
 
-@pytest.mark.parametrize("d", [64, 128])
+@pytest.mark.parametrize("d,prec", [(64, "f32"), (64, "f16x2"), (24, "f16x2"), (128, "f32")])
 @pytest.mark.parametrize("n", [1, 15, 16, 17, 127, 128, 129, 1000, 4099])
-def test_dense_kernel_row_count_edges(d, n):
+def test_dense_kernel_row_count_edges(d, prec, n):
     """rg_dense_fwd / rg_dense_fwd_dev straight through the engine on row counts around the 16-node tile and the 128-node round
     of the streamed d=128 kernel, with and without old nodes, middle layer (a_s out) and last layer (readout), against torch."""
     from red_gnn_amd import engine
@@ -1123,11 +1127,12 @@ def test_dense_kernel_row_count_edges(d, n):
     with torch.no_grad():
         for prev_idx in (prev, None):
             h_ref, as_ref, sc_ref = reference(prev_idx)
-            h1, a1 = engine.dense_fwd(agg, hprev, prev_idx, d, W_h, "tanh", gate, Ws_next=Ws, attn_dim=a, ap=ap)
+            h1, a1 = engine.dense_fwd(agg, hprev, prev_idx, d, W_h, "tanh", gate, Ws_next=Ws, attn_dim=a, ap=ap, precision=prec)
             np.testing.assert_allclose(h1.cpu().numpy(), h_ref.cpu().numpy(), rtol=RTOL, atol=ATOL_H)
             np.testing.assert_allclose(a1[:, :a].cpu().numpy(), as_ref.cpu().numpy(), rtol=RTOL, atol=ATOL_H)
             scores = torch.zeros(n_q * n_ent, device=dev)
-            h2, _ = engine.dense_fwd(agg, hprev, prev_idx, d, W_h, "tanh", gate, W_final=W_final, nodes=nodes, n_ent=n_ent, scores_all=scores)
+            h2, _ = engine.dense_fwd(agg, hprev, prev_idx, d, W_h, "tanh", gate, W_final=W_final, nodes=nodes, n_ent=n_ent, scores_all=scores,
+                                     precision=prec)
             assert torch.equal(h1, h2)
             np.testing.assert_allclose(scores[:n].cpu().numpy(), sc_ref.cpu().numpy(), rtol=RTOL, atol=ATOL_H)
             assert not scores[n:].any()
@@ -1140,14 +1145,14 @@ def test_dense_kernel_row_count_edges(d, n):
         count = torch.tensor([n, 0, 0, 0], dtype=torch.int32, device=dev)
         import ctypes
         engine.dense_fwd_dev(cap, ctypes.c_void_p(count.data_ptr()), agg_c, hprev, prev_c, d, W_h, "tanh", gate, out, Ws_next=Ws, attn_dim=a,
-                             ap=ap, a_s_out=a_out)
+                             ap=ap, a_s_out=a_out, precision=prec)
         h_ref, as_ref, _ = reference(prev)
         np.testing.assert_allclose(out[:n].cpu().numpy(), h_ref.cpu().numpy(), rtol=RTOL, atol=ATOL_H)
         assert bool((out[n:] == -7.0).all()) and bool((a_out[n:] == -7.0).all())
         # n_hint only sizes the grid: far too small an expectation still processes every row
         out2 = torch.full((cap, d), -7.0, device=dev)
         engine.dense_fwd_dev(cap, ctypes.c_void_p(count.data_ptr()), agg_c, hprev, prev_c, d, W_h, "tanh", gate, out2, Ws_next=Ws, attn_dim=a,
-                             ap=ap, a_s_out=a_out, n_hint=max(1, n // 7))
+                             ap=ap, a_s_out=a_out, n_hint=max(1, n // 7), precision=prec)
         assert torch.equal(out2, out)
 
 
