@@ -29,11 +29,27 @@ constexpr int DENSE_T = 512;
 constexpr float LOG2E = 1.44269504088896340736f;
 
 // hi / lo halves of four (already scaled) floats
+// (the residual x - float(hi) as one v_fma_mix_f32 per value - hi read as f16 in place - instead of a conversion and a subtraction:
+// the compiler does not form it, and the splits are a third of the kernel's vector instructions)
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float resid_lo(h2 hi, float x) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hi), "v"(x));
+  return r;
+}
+__device__ __forceinline__ float resid_hi(h2 hi, float x) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hi), "v"(x));
+  return r;
+}
+typedef float f2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split4(float a, float b, float c, float d, h4& hi, h4& lo) {
-  const f4v x = {a, b, c, d};
-  hi = __builtin_convertvector(x, h4);
-  const f4v r = x - __builtin_convertvector(hi, f4v);
-  lo = __builtin_convertvector(r, h4);
+  const f2v x0 = {a, b}, x1 = {c, d};
+  const h2 h0 = __builtin_convertvector(x0, h2), h1 = __builtin_convertvector(x1, h2);
+  const f2v r0 = {resid_lo(h0, a), resid_hi(h0, b)}, r1 = {resid_lo(h1, c), resid_hi(h1, d)};
+  const h2 l0 = __builtin_convertvector(r0, h2), l1 = __builtin_convertvector(r1, h2);
+  hi = __builtin_shufflevector(h0, h1, 0, 1, 2, 3);
+  lo = __builtin_shufflevector(l0, l1, 0, 1, 2, 3);
 }
 
 // power-of-two scale that puts m (>= 0) into [2^14, 2^15), and its inverse; rows of (near) zeros keep a finite scale
@@ -172,18 +188,25 @@ __global__ __launch_bounds__(DENSE_T, 2) void dense_split_kernel(DenseArgs A) {
   // the lane's A-fragment slot of k-step s in a 16-row block (block bases are multiples of 16 rows: the swizzle depends on li only).
   // Kept as byte offsets that the tile loop re-launders every iteration, so that each fragment read is one ds_read_b128 with the
   // image / block offset as its immediate (hoisted out of the loop, the 116 addresses of a tile would each take a register).
-  uint32_t a_off[KST];
+  uint32_t a_off[KST], b_off[KST];
 #pragma unroll
-  for (int s = 0; s < KST; ++s) a_off[s] = (uint32_t)G::at(li, 4 * s + hq) * 16u;
+  for (int s = 0; s < KST; ++s) { a_off[s] = (uint32_t)G::at(li, 4 * s + hq) * 16u; b_off[s] = a_off[s] + 65536u; }
   const char* wbase = reinterpret_cast<const char*>(lds);
   // acc += the 16-row block at row0 of a weight image times the fragment
-  auto mma = [&](const h8* hi_img, const h8* lo_img, int row0, const h8 (&fh)[KST], const h8 (&fl)[KST], f32x4& acc) {
-    const uint32_t o_hi = (uint32_t)(reinterpret_cast<const char*>(hi_img) - wbase) + (uint32_t)row0 * SR * 16u;
-    const uint32_t o_lo = (uint32_t)(reinterpret_cast<const char*>(lo_img) - wbase) + (uint32_t)row0 * SR * 16u;
+  // byte offsets of the image parts from the start of LDS
+  constexpr uint32_t O_WH = 0, O_WIH = 2 * IMG * 16, O_WHH = O_WIH + 6 * IMG * 16, O_E = O_WHH + 6 * IMG * 16;
+  constexpr uint32_t P_W = IMG * 16, P_G = 3 * IMG * 16, P_E = 32 * SR * 16;      // hi -> lo distance of W_h, of a gate stack, of E
+  // acc += the 16-row block at row0 of the image at byte offset o_hi (its lo part at o_lo) times the fragment
+  auto mma = [&](uint32_t o_hi, uint32_t o_lo, int row0, const h8 (&fh)[KST], const h8 (&fl)[KST], f32x4& acc) {
+    o_hi += (uint32_t)row0 * SR * 16u;
+    o_lo += (uint32_t)row0 * SR * 16u;
 #pragma unroll
     for (int s = 0; s < KST; ++s) {
-      const h8 wh = *reinterpret_cast<const h8*>(wbase + (a_off[s] + o_hi));
-      const h8 wl = *reinterpret_cast<const h8*>(wbase + (a_off[s] + o_lo));
+      // (a ds offset reaches 64 KiB: images beyond it go through the second base)
+      const h8 wh = o_hi < 65536u ? *reinterpret_cast<const h8*>(wbase + (a_off[s] + o_hi))
+                                  : *reinterpret_cast<const h8*>(wbase + (b_off[s] + (o_hi - 65536u)));
+      const h8 wl = o_lo < 65536u ? *reinterpret_cast<const h8*>(wbase + (a_off[s] + o_lo))
+                                  : *reinterpret_cast<const h8*>(wbase + (b_off[s] + (o_lo - 65536u)));
       acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, fh[s], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, fl[s], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, fh[s], acc, 0, 0, 0);
@@ -231,7 +254,7 @@ __global__ __launch_bounds__(DENSE_T, 2) void dense_split_kernel(DenseArgs A) {
     const int ts = __builtin_amdgcn_readfirstlane(t);
     const int64_t row0 = (int64_t)ts * 16;
 #pragma unroll
-    for (int s = 0; s < KST; ++s) asm volatile("" : "+v"(a_off[s]));
+    for (int s = 0; s < KST; ++s) { asm volatile("" : "+v"(a_off[s])); asm volatile("" : "+v"(b_off[s])); }
     asm volatile("" : "+v"(lane_off));
     const bool node_ok = row0 + li < A.n;
     const bool any_old = __ballot(p_cur >= 0) != 0ull;
@@ -265,7 +288,7 @@ __global__ __launch_bounds__(DENSE_T, 2) void dense_split_kernel(DenseArgs A) {
 #pragma unroll
       for (int ob = 0; ob < NB; ++ob) {
         f32x4 acc = zero4;
-        mma(Wh_hi, Wh_lo, 16 * ob, fh, fl, acc);
+        mma(O_WH, O_WH + P_W, 16 * ob, fh, fl, acc);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float v = acc[r] * sc_out;
@@ -301,12 +324,12 @@ __global__ __launch_bounds__(DENSE_T, 2) void dense_split_kernel(DenseArgs A) {
 #pragma unroll
       for (int ob = 0; ob < NB; ++ob) {
         f32x4 ar = zero4, az = zero4, ai = zero4, ag = zero4;
-        mma(Wih_hi, Wih_lo, 0 * DP + 16 * ob, xh, xl, ar);
-        if constexpr (OLD) mma(Whh_hi, Whh_lo, 0 * DP + 16 * ob, hh, hl, ar);
-        mma(Wih_hi, Wih_lo, 1 * DP + 16 * ob, xh, xl, az);
-        if constexpr (OLD) mma(Whh_hi, Whh_lo, 1 * DP + 16 * ob, hh, hl, az);
-        mma(Wih_hi, Wih_lo, 2 * DP + 16 * ob, xh, xl, ai);
-        if constexpr (OLD) mma(Whh_hi, Whh_lo, 2 * DP + 16 * ob, hh, hl, ag);
+        mma(O_WIH, O_WIH + P_G, 0 * DP + 16 * ob, xh, xl, ar);
+        if constexpr (OLD) mma(O_WHH, O_WHH + P_G, 0 * DP + 16 * ob, hh, hl, ar);
+        mma(O_WIH, O_WIH + P_G, 1 * DP + 16 * ob, xh, xl, az);
+        if constexpr (OLD) mma(O_WHH, O_WHH + P_G, 1 * DP + 16 * ob, hh, hl, az);
+        mma(O_WIH, O_WIH + P_G, 2 * DP + 16 * ob, xh, xl, ai);
+        if constexpr (OLD) mma(O_WHH, O_WHH + P_G, 2 * DP + 16 * ob, hh, hl, ag);
         const float4 br = *reinterpret_cast<const float4*>(bias_l + 0 * DP + 16 * ob + 4 * hq);
         const float4 bz = *reinterpret_cast<const float4*>(bias_l + 1 * DP + 16 * ob + 4 * hq);
         const float4 bi = *reinterpret_cast<const float4*>(bias_l + 2 * DP + 16 * ob + 4 * hq);
@@ -344,13 +367,13 @@ __global__ __launch_bounds__(DENSE_T, 2) void dense_split_kernel(DenseArgs A) {
     // ---- projections of the new state --------------------------------------------------------------------------------------------
     if (A.Ws) {       // rows e = 4*hq + r of block 0
       f32x4 acc = zero4;
-      mma(E_hi, E_lo, 0, nh, nl, acc);
+      mma(O_E, O_E + P_E, 0, nh, nl, acc);
       if (node_ok && 4 * hq < A.ap)
         reinterpret_cast<float4*>(A.a_s_out + node * A.ap)[hq] = make_float4(acc[0] * inv_w, acc[1] * inv_w, acc[2] * inv_w, acc[3] * inv_w);
     }
     if (A.W_final) {  // row 16 = register 0 of quarter 0 of block 1
       f32x4 acc = zero4;
-      mma(E_hi, E_lo, 16, nh, nl, acc);
+      mma(O_E, O_E + P_E, 16, nh, nl, acc);
       if (node_ok && hq == 0) A.scores[(int64_t)qe.x * A.n_ent + qe.y] = acc[0] * inv_w;
     }
   }
