@@ -32,6 +32,7 @@ if ROOT not in sys.path:
 HBM_PEAK = 8.0e12          # B/s, /opt/skills/guides/MI355X_MICROARCH.md (spec; ~6.3e12 achievable)
 L2_GATHER_PEAK = 18.8e12   # B/s, same guide, "Indexed rows": rows shared by every workgroup served by the XCDs' L2s, 16.8-18.8 TB/s chip-wide
 MFMA_F32_PEAK = 157.3e12   # FLOP/s, same guide: f32-input MFMA = the FP32 vector rate
+MFMA_F16_PEAK = 2.5e15     # FLOP/s, same guide: dense f16 / bf16 MFMA
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic_layer_fwd.json")
 
 
@@ -44,6 +45,35 @@ class Params:
 def algorithmic_bytes(n_edges, n_nodes, d):
     """per edge one fp32 source row (4d B) + four int32 indices (16 B); per output node one fp32 row."""
     return n_edges * (4 * d + 16) + n_nodes * 4 * d
+
+
+def dense_roofline(dense_ms, d, attn_dim, n_layer, batch, precision):
+    """Second kernel of the step (W_h + act + GRU + projections + readout, rg_dense_fwd), from its launches' HIP events.
+    Useful flops per node row (what the reference computes): 2 d d (1 + 3 + 3) for W_h, weight_ih, weight_hh + 2 d attn_dim for the
+    hoisted Ws_attn.  Algorithmic bytes per launch: every row's agg in and new state out (8 d), prev_idx (4), a_s out (4 attn_dim
+    padded to 4 floats) and one old-state row per node of the previous level (4 d).
+    precision "f32": products on v_mfma_f32_16x16x4_f32 - the matrix pipe bounds the kernel, peak 157.3 TFLOP/s.
+    precision "f16x2": each product is three f16 MFMAs on two-term splits - the matrix pipe is issued 3x the useful flops at 16x the
+    rate and no longer binds; the kernel is priced against HBM by its rows, with the issued f16 rate beside it."""
+    ms = sum(m for m, _ in dense_ms)
+    rows = sum(n for _, n in dense_ms)
+    flops = rows * (2.0 * d * d * 7 + 2.0 * d * attn_dim)
+    ap = (attn_dim + 3) // 4 * 4
+    nbytes = 0.0
+    for i, (_, n) in enumerate(dense_ms):
+        n_old = batch if i % n_layer == 0 else dense_ms[i - 1][1]
+        nbytes += n * (8.0 * d + 4 + 4 * ap) + n_old * 4.0 * d
+    common = dict(launches=len(dense_ms), avg_launch_ms=ms / len(dense_ms), algorithmic_flops_per_launch=flops / len(dense_ms),
+                  algorithmic_bytes_per_launch=nbytes / len(dense_ms), useful_tflops=flops / (ms * 1e-3) / 1e12, precision=precision,
+                  traffic=None)
+    if precision == "f32":
+        return dict(bound="mfma", kernel="dense_kernel", achieved=flops / (ms * 1e-3) / 1e12, peak=MFMA_F32_PEAK / 1e12, unit="TFLOP/s",
+                    frac=flops / (ms * 1e-3) / MFMA_F32_PEAK, **common)
+    return dict(bound="hbm", kernel="dense_split_kernel", achieved=nbytes / (ms * 1e-3) / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s",
+                frac=nbytes / (ms * 1e-3) / HBM_PEAK,
+                mfma=dict(issued_f16_tflops=3 * flops / (ms * 1e-3) / 1e12, peak=MFMA_F16_PEAK / 1e12,
+                          frac=3 * flops / (ms * 1e-3) / MFMA_F16_PEAK, useful_over_f32_mfma_peak=flops / (ms * 1e-3) / MFMA_F32_PEAK),
+                **common)
 
 
 def stored_traffic(config, batch, version, path=TRAFFIC_FILE):
@@ -330,8 +360,38 @@ def main():
     # per-launch records before anything else touches the event lists
     ev_ms = [(e0.elapsed_time(e1), ne, nn) for (e0, e1, ne, nn) in kernel_events]
     dense_ms = [(e0.elapsed_time(e1), n) for (e0, e1, n) in dense_events]
+    last_default = dict(last)          # the timed region's last scores (default precision)
     gpu_scores = last["scores"].cpu().numpy() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
     gpu_ranks = last["ranks"].double().cpu().numpy() if gpu_scores is not None else None
+
+    # the same step with the dense kernel's products on exact-fp32 MFMA (after the timed region; the default is the f16-split form)
+    dense_f32 = None
+    if d <= 64 and model.dense_precision != "f32" and not args.graphs:
+        saved_prec, saved_ev = model.dense_precision, (engine.KERNEL_EVENTS, engine.DENSE_EVENTS)
+        model.dense_precision = "f32"
+        engine.KERNEL_EVENTS = engine.DENSE_EVENTS = None
+        k2 = max(1, min(args.steps, 10))
+        step()
+        while pending:
+            pending.pop()[0].wait()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(k2):
+            step()
+        while pending:
+            pending.pop()[0].wait()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t2 = torch.tensor([time.perf_counter() - t1], device="cuda", dtype=torch.float64)
+        if dist is not None:
+            dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+        dense_f32 = dict(ms_per_step=float(t2[0]) / k2 * 1e3, steps=k2, value=total_edges / args.steps * k2 / float(t2[0]),
+                         max_abs_score_diff_to_default=float((last["scores"] - last_default["scores"]).abs().max()))
+        model.dense_precision = saved_prec
+        engine.KERNEL_EVENTS, engine.DENSE_EVENTS = saved_ev
 
     # second half of the metric's name, after (never inside) the timed region
     family = None if args.no_family_eval else family_eval(dist, world, engine)
@@ -339,16 +399,8 @@ def main():
     if rank == 0:
         version = int(_lib.lib().rg_version())
         roof, roof_l2, per_hop = layer_rooflines(ev_ms, d, shape["n_layer"], stored_traffic(args.config, B, version))
-        roof_dense = None
-        if dense_ms:
-            # second kernel of the step: W_h + GRU + projections on f32 MFMA.  Algorithmic flops per node (what the
-            # reference computes): 2*d*d*(1 + 3 + 3) for W_h, weight_ih, weight_hh, + 2*d*attn_dim for the hoisted Ws_attn
-            d_ms = sum(m for m, _ in dense_ms)
-            rows = sum(n for _, n in dense_ms)
-            flops = rows * (2.0 * d * d * 7 + 2.0 * d * shape["attn_dim"])
-            roof_dense = dict(bound="mfma", kernel="dense_kernel", achieved=flops / (d_ms * 1e-3) / 1e12, peak=MFMA_F32_PEAK / 1e12,
-                              unit="TFLOP/s", frac=flops / (d_ms * 1e-3) / MFMA_F32_PEAK, traffic=None, launches=len(dense_ms),
-                              avg_launch_ms=d_ms / len(dense_ms), algorithmic_flops_per_launch=flops / len(dense_ms))
+        roof_dense = dense_roofline(dense_ms, d, shape["attn_dim"], shape["n_layer"], B,
+                                    model.dense_precision if d <= 64 else "f32") if dense_ms else None
         cpu = parity = None
         if gpu_scores is not None:
             query, answer = loader.test_q, loader.test_a
@@ -362,6 +414,9 @@ def main():
             "value": total_edges / dt, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "dense_precision": ("f16x2: fp32 operands as two-term f16 splits (22 bits), fp32 accumulation; dense_f32 = the same step with "
+                                "exact-fp32 MFMA products" if (d <= 64 and model.dense_precision == "f16x2") else "f32"),
+            "dense_f32": dense_f32,
             "config": {"workload": "%s synthetic KG %d entities / %d relations / %d triples (seed 1234), n_layer=%d hidden_dim=%d attn_dim=%d, "
                                    "eval step = expansion + fused layers + GRU/readout + filtered ranking, %d queries per GPU"
                                    % (args.config, kg.n_ent, kg.n_rel, shape["n_triples"], shape["n_layer"], d, shape["attn_dim"], B),

@@ -262,6 +262,21 @@ def test_bench_roofline_objects():
     assert _lib.lib().rg_version() >= 2
 
 
+def test_bench_dense_roofline_per_precision():
+    """bench.dense_roofline prices the exact-fp32 dense kernel against the f32 matrix pipe and the f16-split kernel against HBM by its
+    rows (with the issued f16 MFMA rate beside it): launches of C2 / B=1024 as measured in round 2."""
+    import bench
+    rows = [1.3e6, 8.2e6, 10.0e6]
+    f32 = bench.dense_roofline([(0.5, rows[0]), (3.2, rows[1]), (3.9, rows[2])] * 2, 64, 5, 3, 1024, "f32")
+    assert f32["bound"] == "mfma" and f32["kernel"] == "dense_kernel" and f32["peak"] == 157.3 and 0.5 < f32["frac"] < 1.0
+    sp = bench.dense_roofline([(0.2, rows[0]), (1.0, rows[1]), (1.22, rows[2])] * 2, 64, 5, 3, 1024, "f16x2")
+    assert sp["bound"] == "hbm" and sp["kernel"] == "dense_split_kernel" and sp["unit"] == "GB/s" and 0.0 < sp["frac"] < 1.0
+    per_launch = (sum(rows) * (8 * 64 + 4 + 32) + (1024 + rows[0] + rows[1]) * 256) / 3
+    assert abs(sp["algorithmic_bytes_per_launch"] - per_launch) < 1e-6 * per_launch
+    assert abs(sp["mfma"]["issued_f16_tflops"] - 3 * sp["useful_tflops"]) < 1e-9 and sp["mfma"]["frac"] < 1.0
+    assert sp["mfma"]["useful_over_f32_mfma_peak"] > 1.0          # more useful flops per second than the f32 pipe could issue
+
+
 def test_loader_id_cache_roundtrip():
     """Binary id cache of the parsed text: second construction reads the cache, same loader state."""
     from red_gnn_amd.load_data import DataLoader
