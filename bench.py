@@ -242,6 +242,8 @@ def main():
     ap.add_argument("--config", default="C2")
     ap.add_argument("--dense-precision", default=None, choices=["f32", "f16x2"],
                     help="matrix products of the fused dense kernel (default: the model's default)")
+    ap.add_argument("--no-dense-f32", action="store_true", help="skip the secondary measurement of the step with exact-fp32 dense products "
+                    "(profiling runs: keeps the launch sequence to the timed steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-family-eval", action="store_true", help="skip BaseModel.evaluate on the real family graph (runs after the timed region "
@@ -366,7 +368,7 @@ def main():
 
     # the same step with the dense kernel's products on exact-fp32 MFMA (after the timed region; the default is the f16-split form)
     dense_f32 = None
-    if d <= 64 and model.dense_precision != "f32" and not args.graphs:
+    if d <= 64 and model.dense_precision != "f32" and not args.graphs and not args.no_dense_f32:
         saved_prec, saved_ev = model.dense_precision, (engine.KERNEL_EVENTS, engine.DENSE_EVENTS)
         model.dense_precision = "f32"
         engine.KERNEL_EVENTS = engine.DENSE_EVENTS = None
@@ -399,8 +401,14 @@ def main():
     if rank == 0:
         version = int(_lib.lib().rg_version())
         roof, roof_l2, per_hop = layer_rooflines(ev_ms, d, shape["n_layer"], stored_traffic(args.config, B, version))
+        traffic_entry = stored_traffic(args.config, B, version)
         roof_dense = dense_roofline(dense_ms, d, shape["attn_dim"], shape["n_layer"], B,
                                     model.dense_precision if d <= 64 else "f32") if dense_ms else None
+        if roof_dense and traffic_entry:
+            for name, rec in traffic_entry.get("dense", {}).items():          # the same PMC passes also saw the dense launches
+                if name.endswith(roof_dense["kernel"]):
+                    roof_dense["traffic"] = rec["hbm_bytes_per_launch"]
+                    roof_dense["hbm_measured_frac"] = rec["hbm_bytes_per_launch"] / (roof_dense["avg_launch_ms"] * 1e-3) / HBM_PEAK
         cpu = parity = None
         if gpu_scores is not None:
             query, answer = loader.test_q, loader.test_a
