@@ -11,7 +11,7 @@ What is different inside (nothing is different outside):
     its adjoint rg_layer_bwd; the three attention Linear layers are hoisted to per-node /
     per-relation / per-query projections (exact re-association, SURVEY.md §9);
   * dense algebra that is not on the E-proportional path (W_h, GRU cell, hoisted projections, W_final): inference runs it
-    in one f32-MFMA kernel per layer (rg_dense_fwd), and from the third call of a (graph, batch size) on replays the whole
+    in one matrix-core kernel per layer (rg_dense_fwd: f16-split products by default, see dense_precision), and from the third call of a (graph, batch size) on replays the whole
     forward as one captured HIP graph (_GraphedInference); training runs W_h + act + carry + dropout + GRU step as one kernel
     too (_DenseStep: rg_dense_train_fwd / rg_dense_train_bwd), with the weight gradients - sums over millions of node rows -
     issued as row-chunked batched GEMMs (``tall_linear`` / ``_gram_tn``: a plain [m,n] = G^T X product lands on a handful of

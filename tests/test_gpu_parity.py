@@ -1156,6 +1156,41 @@ def test_dense_kernel_row_count_edges(d, prec, n):
         assert torch.equal(out2, out)
 
 
+@pytest.mark.parametrize("scale", [1e-6, 1e-3, 1.0, 300.0])
+def test_split_dense_kernel_fits_its_weight_scale(scale):
+    """The f16-split dense kernel stages all weights under one power-of-two scale: 2^12 by default, refitted in a second staging pass
+    when the weights' largest magnitude would overflow f16 or leave the lo halves denormal.  Both paths against fp64, at the same
+    tolerance as unit-scale weights (relative to each output's magnitude)."""
+    from red_gnn_amd import engine
+    torch.manual_seed(11)
+    dev, n, d, a, ap = "cuda", 3000, 64, 5, 8
+    agg = torch.randn(n, d, device=dev)
+    hprev = torch.tanh(torch.randn(n // 2, d, device=dev))
+    prev = torch.randint(-1, n // 2, (n,), device=dev, dtype=torch.int32)
+    gate = torch.nn.GRU(d, d).to(dev)
+    small = min(scale, 1.0)        # (large gate weights saturate the gates and make the comparison ill-conditioned: the large case
+    with torch.no_grad():          # scales the projection only, which is enough to push the largest weight past the default scale)
+        for p_ in gate.parameters():
+            p_.mul_(small)
+    W_h = torch.randn(d, d, device=dev) / d ** 0.5 * small
+    Ws = torch.randn(a, d, device=dev) / d ** 0.5 * scale
+    f = lambda t: t.double()
+    with torch.no_grad():
+        x = f(agg) @ f(W_h).t()
+        h0 = torch.zeros(n, d, device=dev, dtype=torch.float64)
+        m = prev >= 0
+        h0[m] = f(hprev)[prev[m].long()]
+        gi = x @ f(gate.weight_ih_l0).t() + f(gate.bias_ih_l0)
+        gh = h0 @ f(gate.weight_hh_l0).t() + f(gate.bias_hh_l0)
+        r, z = torch.sigmoid(gi[:, :d] + gh[:, :d]), torch.sigmoid(gi[:, d:2 * d] + gh[:, d:2 * d])
+        h_ref = (1 - z) * torch.tanh(gi[:, 2 * d:] + r * gh[:, 2 * d:]) + z * h0
+        as_ref = h_ref @ f(Ws).t()
+        for prec in ("f16x2", "f32"):
+            h, a_s = engine.dense_fwd(agg, hprev, prev, d, W_h, "idd", gate, Ws_next=Ws, attn_dim=a, ap=ap, precision=prec)
+            assert float((h.double() - h_ref).abs().max()) < 2e-6 * max(1.0, float(h_ref.abs().max())), (prec, scale)
+            assert float((a_s[:, :a].double() - as_ref).abs().max()) < 2e-6 * max(scale, float(as_ref.abs().max())), (prec, scale)
+
+
 def test_graph_replay_inductive_switches_graphs():
     """RED_GNN_induc evaluates on two graphs of different entity counts (mode 'transductive' / 'inductive'); the replayed
     HIP graphs are keyed by the device graph and equal the eager path on both."""
