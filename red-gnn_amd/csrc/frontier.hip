@@ -480,10 +480,18 @@ static int enqueue_expand(rg_frontier* f, const rg_graph* g, hipStream_t s, int3
   const int64_t nw = (int64_t)f->B * f->W;
   const int2* bm_old = f->bm_of(f->level - 1);
   if (nw <= SMALL_MAX_WORDS) {
+    // one workgroup writes a node list at one CU's store rate (64 B/clk: the 150 k nodes of a saturated 50-query family level took 20 of
+    // the kernel's 29 us, on the dependent chain of every replayed forward): past a few thousand words the list is a launch of its own
+    const bool split_emit = (nodes || prev_idx) && nw > 1024;
     hipLaunchKernelGGL(build_level_small_kernel, dim3(1), dim3(SMALL_T), (size_t)nw * 4, s, f->bitsT[f->tcur], f->n_ent, f->B, f->BW,
-                       f->W, (f->W + 1) / 2, f->bm[f->level % f->n_levels], bm_old, f->counters, f->queues, slot, nodes, prev_idx,
-                       (int32_t*)nullptr);
+                       f->W, (f->W + 1) / 2, f->bm[f->level % f->n_levels], bm_old, f->counters, f->queues, slot,
+                       split_emit ? (int32_t*)nullptr : nodes, split_emit ? (int32_t*)nullptr : prev_idx, (int32_t*)nullptr);
     RG_LAUNCH_CHECK();
+    if (split_emit) {
+      hipLaunchKernelGGL(emit_nodes_kernel, dim3(rg::ceil_div(nw * 32, 256)), dim3(256), 0, s, f->bm_of(f->level), bm_old, f->B, f->W,
+                         nodes, prev_idx, (int32_t*)nullptr);
+      RG_LAUNCH_CHECK();
+    }
   } else {
     if (build_level(f, s)) return 1;
     hipLaunchKernelGGL(snapshot_kernel, dim3(1), dim3(64), 0, s, f->counters, f->queues, slot);
