@@ -67,9 +67,11 @@ def dense_roofline(dense_ms, d, attn_dim, n_layer, batch, precision):
                   algorithmic_bytes_per_launch=nbytes / len(dense_ms), useful_tflops=flops / (ms * 1e-3) / 1e12, precision=precision,
                   traffic=None)
     if precision == "f32":
-        return dict(bound="mfma", kernel="dense_kernel", achieved=flops / (ms * 1e-3) / 1e12, peak=MFMA_F32_PEAK / 1e12, unit="TFLOP/s",
+        return dict(bound="mfma", kernel="dense_kernel" if d <= 64 else "dense128_kernel", achieved=flops / (ms * 1e-3) / 1e12,
+                    peak=MFMA_F32_PEAK / 1e12, unit="TFLOP/s",
                     frac=flops / (ms * 1e-3) / MFMA_F32_PEAK, **common)
-    return dict(bound="hbm", kernel="dense_split_kernel", achieved=nbytes / (ms * 1e-3) / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s",
+    return dict(bound="hbm", kernel="dense_split_kernel" if d <= 64 else "dense128_split_kernel", achieved=nbytes / (ms * 1e-3) / 1e9,
+                peak=HBM_PEAK / 1e9, unit="GB/s",
                 frac=nbytes / (ms * 1e-3) / HBM_PEAK,
                 mfma=dict(issued_f16_tflops=3 * flops / (ms * 1e-3) / 1e12, peak=MFMA_F16_PEAK / 1e12,
                           frac=3 * flops / (ms * 1e-3) / MFMA_F16_PEAK, useful_over_f32_mfma_peak=flops / (ms * 1e-3) / MFMA_F32_PEAK),
@@ -368,7 +370,7 @@ def main():
 
     # the same step with the dense kernel's products on exact-fp32 MFMA (after the timed region; the default is the f16-split form)
     dense_f32 = None
-    if d <= 64 and model.dense_precision != "f32" and not args.graphs and not args.no_dense_f32:
+    if model.dense_precision != "f32" and not args.graphs and not args.no_dense_f32:
         saved_prec, saved_ev = model.dense_precision, (engine.KERNEL_EVENTS, engine.DENSE_EVENTS)
         model.dense_precision = "f32"
         engine.KERNEL_EVENTS = engine.DENSE_EVENTS = None
@@ -402,8 +404,7 @@ def main():
         version = int(_lib.lib().rg_version())
         roof, roof_l2, per_hop = layer_rooflines(ev_ms, d, shape["n_layer"], stored_traffic(args.config, B, version))
         traffic_entry = stored_traffic(args.config, B, version)
-        roof_dense = dense_roofline(dense_ms, d, shape["attn_dim"], shape["n_layer"], B,
-                                    model.dense_precision if d <= 64 else "f32") if dense_ms else None
+        roof_dense = dense_roofline(dense_ms, d, shape["attn_dim"], shape["n_layer"], B, model.dense_precision) if dense_ms else None
         if roof_dense and traffic_entry:
             for name, rec in traffic_entry.get("dense", {}).items():          # the same PMC passes also saw the dense launches
                 if name.endswith(roof_dense["kernel"]):
@@ -423,7 +424,7 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "dense_precision": ("f16x2: fp32 operands as two-term f16 splits (22 bits), fp32 accumulation; dense_f32 = the same step with "
-                                "exact-fp32 MFMA products" if (d <= 64 and model.dense_precision == "f16x2") else "f32"),
+                                "exact-fp32 MFMA products" if model.dense_precision == "f16x2" else "f32"),
             "dense_f32": dense_f32,
             "config": {"workload": "%s synthetic KG %d entities / %d relations / %d triples (seed 1234), n_layer=%d hidden_dim=%d attn_dim=%d, "
                                    "eval step = expansion + fused layers + GRU/readout + filtered ranking, %d queries per GPU"

@@ -233,12 +233,15 @@ int rg_dense_fwd(int64_t n, int32_t d, int32_t ld, const float* agg, const float
                  const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
                  const float* Ws_next, int32_t attn_dim, int32_t ap, float* a_s_out,
                  const float* W_final, const int32_t* nodes, int32_t n_ent, float* scores_all,
-                 float* hidden_out, int32_t precision, void* stream);
+                 float* hidden_out, int32_t precision, void* scratch, int64_t scratch_bytes, void* stream);
+/* scratch: device memory of rg_dense_scratch_bytes(d, precision) bytes, 256-B aligned (0 bytes / NULL for every case but d = 128 with
+ * precision 1, whose weights stream through LDS from a split image written there first).  Contents are dead after the call. */
+int64_t rg_dense_scratch_bytes(int32_t d, int32_t precision);
 /* precision: how the matrix products are evaluated.
  *   0  v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulation (what the reference's fp32 GEMMs compute up to sum order)
  *   1  every fp32 operand as a two-term f16 split (22 significant bits, per-row power-of-two scaling), three
  *      v_mfma_f32_16x16x32_f16 per product with fp32 accumulation: errors of a few 1e-7 of a dot product's largest terms instead
- *      of 1e-7, at 3/16 of the matrix-pipe time (d <= 64; at d = 128 both settings run the exact kernel) */
+ *      of 1e-7, at 3/16 of the matrix-pipe time */
 
 /* ---- filtered ranking: replaces utils.py:7-14 cal_ranks (+ the filter loop base_model.py:107-115)
  * scores device fp32 [B, n_ent]; answers / filters as CSR over queries (device int32):
@@ -258,7 +261,7 @@ int rg_dense_fwd_dev(int64_t n_cap, const int32_t* n_dev, int64_t n_hint, int32_
                      const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
                      const float* Ws_next, int32_t attn_dim, int32_t ap, float* a_s_out,
                      const float* W_final, const int32_t* nodes, int32_t n_ent, float* scores_all,
-                     float* hidden_out, int32_t precision, void* stream);
+                     float* hidden_out, int32_t precision, void* scratch, int64_t scratch_bytes, void* stream);
 
 /* ---- dense step of a layer in training: models.py:41 (W_h + act), :81 (h0 carry), :82 (dropout, as a given mask: 0 or
  * 1/(1-p) per element, or NULL), :83 (single-step GRU) in one f32-MFMA kernel that also leaves what the backward pass needs:

@@ -330,13 +330,17 @@ int launch(const DenseArgs& A, hipStream_t s) {
 
 }  // namespace
 
+extern "C" int64_t rg_dense_scratch_bytes(int32_t d, int32_t precision) {
+  return d == 128 && precision == 1 ? rg::dense128_split_scratch_bytes() : 0;
+}
+
 extern "C" int rg_dense_fwd_supported(int32_t d, int32_t attn_dim) { return ((d >= 1 && d <= 64) || d == 128) && attn_dim <= 16; }
 
 static int dense_fwd_impl(int64_t n, const int32_t* n_dev, int64_t n_hint, int32_t d, int32_t ld, const float* agg, const float* hidden_prev,
                           const int32_t* prev_idx, const float* W_h, int32_t act, const float* w_ih, const float* w_hh,
                           const float* b_ih, const float* b_hh, const float* Ws_next, int32_t attn_dim, int32_t ap,
                           float* a_s_out, const float* W_final, const int32_t* nodes, int32_t n_ent, float* scores_all,
-                          float* hidden_out, int32_t precision, void* stream) {
+                          float* hidden_out, int32_t precision, void* scratch, int64_t scratch_bytes, void* stream) {
   RG_CHECK(agg && W_h && w_ih && w_hh && b_ih && b_hh && hidden_out, "rg_dense_fwd: NULL argument");
   RG_CHECK(precision == 0 || precision == 1, "rg_dense_fwd: precision=%d (0 = f32 MFMA, 1 = two-term f16 split)", precision);
   RG_CHECK(!prev_idx || hidden_prev, "rg_dense_fwd: prev_idx given without hidden_prev");
@@ -358,7 +362,7 @@ static int dense_fwd_impl(int64_t n, const int32_t* n_dev, int64_t n_hint, int32
   A.hidden_out = (float4*)hidden_out; A.act = act;
   A.n_tiles = (int)rg::ceil_div(n, 16);
   hipStream_t s = (hipStream_t)stream;
-  if (d == 128) return rg::dense128_launch(A, s);      // (no split form at d = 128 yet: the exact kernel serves both settings)
+  if (d == 128) return precision == 1 ? rg::dense128_split_launch(A, scratch, scratch_bytes, s) : rg::dense128_launch(A, s);
   if (precision == 1) return rg::dense_split_launch(A, s);
   return d <= 32 ? launch<2, false>(A, s) : launch<4, false>(A, s);
 }
@@ -367,19 +371,20 @@ extern "C" int rg_dense_fwd(int64_t n, int32_t d, int32_t ld, const float* agg, 
                             const int32_t* prev_idx, const float* W_h, int32_t act, const float* w_ih, const float* w_hh,
                             const float* b_ih, const float* b_hh, const float* Ws_next, int32_t attn_dim, int32_t ap,
                             float* a_s_out, const float* W_final, const int32_t* nodes, int32_t n_ent, float* scores_all,
-                            float* hidden_out, int32_t precision, void* stream) {
+                            float* hidden_out, int32_t precision, void* scratch, int64_t scratch_bytes, void* stream) {
   return dense_fwd_impl(n, nullptr, 0, d, ld, agg, hidden_prev, prev_idx, W_h, act, w_ih, w_hh, b_ih, b_hh, Ws_next, attn_dim, ap,
-                        a_s_out, W_final, nodes, n_ent, scores_all, hidden_out, precision, stream);
+                        a_s_out, W_final, nodes, n_ent, scores_all, hidden_out, precision, scratch, scratch_bytes, stream);
 }
 
 extern "C" int rg_dense_fwd_dev(int64_t n_cap, const int32_t* n_dev, int64_t n_hint, int32_t d, int32_t ld, const float* agg,
                                 const float* hidden_prev, const int32_t* prev_idx, const float* W_h, int32_t act,
                                 const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, const float* Ws_next,
                                 int32_t attn_dim, int32_t ap, float* a_s_out, const float* W_final, const int32_t* nodes,
-                                int32_t n_ent, float* scores_all, float* hidden_out, int32_t precision, void* stream) {
+                                int32_t n_ent, float* scores_all, float* hidden_out, int32_t precision, void* scratch,
+                                int64_t scratch_bytes, void* stream) {
   RG_CHECK(n_dev != nullptr, "rg_dense_fwd_dev: n_dev is NULL");
   return dense_fwd_impl(n_cap, n_dev, n_hint, d, ld, agg, hidden_prev, prev_idx, W_h, act, w_ih, w_hh, b_ih, b_hh, Ws_next, attn_dim, ap,
-                        a_s_out, W_final, nodes, n_ent, scores_all, hidden_out, precision, stream);
+                        a_s_out, W_final, nodes, n_ent, scores_all, hidden_out, precision, scratch, scratch_bytes, stream);
 }
 
 extern "C" int rg_dense_train_fwd(int64_t n, int32_t d, const float* agg, const float* hidden_prev, const int32_t* prev_idx,

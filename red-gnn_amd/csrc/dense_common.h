@@ -48,5 +48,8 @@ static __device__ __forceinline__ float fast_tanh(float x) {
 int dense128_launch(const DenseArgs& A, hipStream_t s);
 // d <= 64 with the products as two-term f16 splits (dense_split.hip)
 int dense_split_launch(const DenseArgs& A, hipStream_t s);
+// d = 128 with split products: the weights' split image goes through a caller-provided scratch (dense128_split.hip)
+int64_t dense128_split_scratch_bytes();
+int dense128_split_launch(const DenseArgs& A, void* scratch, int64_t scratch_bytes, hipStream_t s);
 
 }  // namespace rg

@@ -450,6 +450,12 @@ def dense_supported(d, attn_dim):
 DENSE_PRECISIONS = {"f32": 0, "f16x2": 1}
 
 
+def dense_scratch(d, precision, device):
+    """Scratch of rg_dense_fwd for this width and precision (d = 128 with split products: the weights' split image), or None."""
+    nbytes = int(_lib.lib().rg_dense_scratch_bytes(d, DENSE_PRECISIONS[precision]))
+    return torch.empty(nbytes, dtype=torch.uint8, device=device) if nbytes else None
+
+
 def dense_fwd(agg, hidden_prev, prev_idx, d, W_h, act, gate, Ws_next=None, attn_dim=0, ap=0, W_final=None, nodes=None,
               n_ent=0, scores_all=None, precision="f32"):
     """Fused W_h + act + GRU step (+ next layer's a_s, + readout) on the matrix cores (rg_dense_fwd).  precision: "f32" = exact
@@ -461,6 +467,7 @@ def dense_fwd(agg, hidden_prev, prev_idx, d, W_h, act, gate, Ws_next=None, attn_
     c = lambda t: None if t is None else t.detach().contiguous()
     W_h, w_ih, w_hh, b_ih, b_hh = c(W_h), c(gate.weight_ih_l0), c(gate.weight_hh_l0), c(gate.bias_ih_l0), c(gate.bias_hh_l0)
     Ws_next, W_final = c(Ws_next), c(W_final)
+    scratch = dense_scratch(d, precision, agg.device)
     ev = None
     if DENSE_EVENTS is not None:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -469,7 +476,7 @@ def dense_fwd(agg, hidden_prev, prev_idx, d, W_h, act, gate, Ws_next=None, attn_
                                        {"idd": 0, "relu": 1, "tanh": 2}[act], _lib.ptr(w_ih), _lib.ptr(w_hh), _lib.ptr(b_ih),
                                        _lib.ptr(b_hh), _lib.ptr(Ws_next), attn_dim, ap, _lib.ptr(a_s), _lib.ptr(W_final),
                                        _lib.ptr(nodes), n_ent, _lib.ptr(scores_all), _lib.ptr(hidden), DENSE_PRECISIONS[precision],
-                                       _lib.stream_ptr()))
+                                       _lib.ptr(scratch), 0 if scratch is None else scratch.numel(), _lib.stream_ptr()))
     if ev is not None:
         ev[1].record()
         DENSE_EVENTS.append((ev[0], ev[1], n))
@@ -477,17 +484,20 @@ def dense_fwd(agg, hidden_prev, prev_idx, d, W_h, act, gate, Ws_next=None, attn_
 
 
 def dense_fwd_dev(n_cap, count_ptr, agg, hidden_prev, prev_idx, d, W_h, act, gate, hidden_out, Ws_next=None, attn_dim=0, ap=0,
-                  a_s_out=None, W_final=None, nodes=None, n_ent=0, scores_all=None, n_hint=0, precision="f32"):
+                  a_s_out=None, W_final=None, nodes=None, n_ent=0, scores_all=None, n_hint=0, precision="f32", scratch=None):
     """rg_dense_fwd_dev: the fused dense epilogue with the row count read on the device (buffers of capacity n_cap)."""
     ld = agg.shape[1]
     c = lambda t: None if t is None else t.detach().contiguous()
     W_h, w_ih, w_hh, b_ih, b_hh = c(W_h), c(gate.weight_ih_l0), c(gate.weight_hh_l0), c(gate.bias_ih_l0), c(gate.bias_hh_l0)
     Ws_next, W_final = c(Ws_next), c(W_final)
+    if scratch is None:
+        scratch = dense_scratch(d, precision, agg.device)
     _lib.check(_lib.lib().rg_dense_fwd_dev(n_cap, count_ptr, int(n_hint), d, ld, _lib.ptr(agg), _lib.ptr(hidden_prev), _lib.ptr(prev_idx),
                                            _lib.ptr(W_h), {"idd": 0, "relu": 1, "tanh": 2}[act], _lib.ptr(w_ih), _lib.ptr(w_hh),
                                            _lib.ptr(b_ih), _lib.ptr(b_hh), _lib.ptr(Ws_next), attn_dim, ap, _lib.ptr(a_s_out),
                                            _lib.ptr(W_final), _lib.ptr(nodes), n_ent, _lib.ptr(scores_all), _lib.ptr(hidden_out),
-                                           DENSE_PRECISIONS[precision], _lib.stream_ptr()))
+                                           DENSE_PRECISIONS[precision], _lib.ptr(scratch), 0 if scratch is None else scratch.numel(),
+                                           _lib.stream_ptr()))
 
 
 def dense_train_supported(d, act):

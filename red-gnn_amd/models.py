@@ -245,6 +245,7 @@ class _GraphedInference:
         self.scores = torch.empty(cap, **f32)
         nbytes = engine.layer_fwd_scratch_bytes(self.fr, graph, self.ld)
         self.scratch = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+        self.dense_scratch = engine.dense_scratch(d, model.dense_precision, device)      # (static: the graph replays its address)
         self.key_ptr = model.W_final.weight.data_ptr()
         side = torch.cuda.Stream(device=device)
         side.wait_stream(torch.cuda.current_stream(device))
@@ -287,7 +288,8 @@ class _GraphedInference:
             engine.dense_fwd_dev(self.cap, fr.count_ptr(), self.agg, hidden, self.prev, d, layer.W_h.weight, m.act_name, m.gate, out_h,
                                  Ws_next=None if last else m.gnn_layers[i + 1].Ws_attn.weight, attn_dim=a, ap=ap,
                                  a_s_out=None if last else out_a, W_final=m.W_final.weight if last else None,
-                                 nodes=self.nodes, n_ent=graph.n_ent, scores_all=self.scores, n_hint=n_hint, precision=m.dense_precision)
+                                 nodes=self.nodes, n_ent=graph.n_ent, scores_all=self.scores, n_hint=n_hint, precision=m.dense_precision,
+                                 scratch=self.dense_scratch)
             hidden, a_s = out_h, out_a
 
     def run(self, q_sub, q_rel):

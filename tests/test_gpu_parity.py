@@ -506,8 +506,6 @@ def test_full_size_properties_c2():
 def test_fused_dense_kernel_matches_torch_dense_path(d, a, act, prec):
     """rg_dense_fwd (W_h + act + GRU + next a_s + readout on the matrix cores, as exact fp32 MFMA and as two-term f16 splits)
     against the same model with the dense part in torch ops (rocBLAS + gru_cell): same nodes, hidden and scores."""
-    if d == 128 and prec == "f16x2":
-        pytest.skip("d = 128 has one kernel for both settings")
     from red_gnn_amd.load_data import DataLoader
     from red_gnn_amd.synthetic import make_synthetic_kg
     kg = make_synthetic_kg(700, 9, 9000, seed=21)
@@ -1096,7 +1094,7 @@ def test_graph_replay_matches_eager_forward():
     assert len(model._graphed) == 1
 
 
-@pytest.mark.parametrize("d,prec", [(64, "f32"), (64, "f16x2"), (24, "f16x2"), (128, "f32")])
+@pytest.mark.parametrize("d,prec", [(64, "f32"), (64, "f16x2"), (24, "f16x2"), (128, "f32"), (128, "f16x2")])
 @pytest.mark.parametrize("n", [1, 15, 16, 17, 127, 128, 129, 1000, 4099])
 def test_dense_kernel_row_count_edges(d, prec, n):
     """rg_dense_fwd / rg_dense_fwd_dev straight through the engine on row counts around the 16-node tile and the 128-node round
