@@ -133,8 +133,8 @@ int rg_frontier_edges(const rg_frontier* f, const rg_graph* g, int32_t level,
  * walk: how the edges are enumerated (the sums and their order are the same; results are bitwise equal):
  *   0  let the library pick from the sizes of the hop (known on the host after rg_frontier_expand);
  *   1  per-query walk: every live destination tests its KG in-edges against the previous frontier;
- *   2, 3, 4, 5  word-parallel walk for hops whose SOURCE frontier is sparse (as the reference expands from the frontier's
- *      nodes, load_data.py:115-118): 32 / 16 / 8 / 4 queries per work item straight from the entity-major bitmaps; only for
+ *   2 .. 7  word-parallel walk for hops whose SOURCE frontier is sparse (as the reference expands from the frontier's
+ *      nodes, load_data.py:115-118): 32 / 16 / 8 / 4 / 2 / 1 queries per work item straight from the entity-major bitmaps; only for
  *      level == the newest hop of a static graph.
  * rg_layer_fwd_plan returns what walk 0 would pick for given sizes (n_old, n_new nodes, n_edges of the hop): callers that
  * enqueue without read-backs (rg_frontier_expand_async) record it from an eager run and pass it explicitly. */

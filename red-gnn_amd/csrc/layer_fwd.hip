@@ -27,6 +27,7 @@ static int plan_walk(const rg_frontier* f, const rg_graph* g, int32_t level, int
   // (more, lighter items) shorten that critical path (family, 50 queries: 800 items of ~170 edges -> 3200 of ~43)
   // (only while an item still carries a few hundred edges: lighter items cost more in tickets and fixed per-item work than they balance)
   auto items = [&](int c) { return (int64_t)f->BW * (1 << (c - 2)) * g->in_pk_packs.n; };
+  // (2 and 1 queries per item - walk codes 6, 7 - measured neutral on family / C3 at 50-64 queries: not picked automatically)
   while (code < 5 && items(code) < 16384 && n_edges > 256 * items(code)) ++code;
   return code;
 }
@@ -44,7 +45,7 @@ extern "C" int rg_layer_fwd(const rg_frontier* f, const rg_graph* g, int32_t lev
   RG_CHECK(f && g && hidden && rela && a_s && a_r && a_q && w_alpha && b_alpha && agg_out, "rg_layer_fwd: NULL argument");
   RG_CHECK((((uintptr_t)hidden | (uintptr_t)rela | (uintptr_t)a_s | (uintptr_t)a_r | (uintptr_t)a_q | (uintptr_t)agg_out |
              (uintptr_t)scratch) & 15) == 0, "rg_layer_fwd: float buffers must be 16-B aligned");
-  RG_CHECK(walk >= 0 && walk <= 5, "rg_layer_fwd: walk=%d not in 0..5", walk);
+  RG_CHECK(walk >= 0 && walk <= 7, "rg_layer_fwd: walk=%d not in 0..7", walk);
   rgfwd::FwdArgs A;
   if (rgfwd::fill_common("rg_layer_fwd", f, g, level, n_new, d, ld, ap, attn_dim, scratch, scratch_bytes,
                          rg_layer_fwd_scratch_bytes(f, g, ld), &A)) return 1;

@@ -402,7 +402,7 @@ def test_two_forwards_before_backward(a):
 @pytest.mark.parametrize("d,a,B,n_ent,m", [(16, 3, 1, 40, 300), (20, 5, 31, 150, 2500), (64, 5, 33, 300, 6000), (48, 12, 70, 90, 4000),
                                            (128, 5, 9, 200, 3000), (256, 20, 5, 120, 1500)])
 def test_word_parallel_walk_bitwise_equals_per_query_walk(d, a, B, n_ent, m):
-    """rg_layer_fwd's two edge walks (per destination / word-parallel from the frontier's nodes, 32, 16, 8 or 4 queries per item)
+    """rg_layer_fwd's two edge walks (per destination / word-parallel from the frontier's nodes, 32, 16, 8, 4, 2 or 1 queries per item)
     enumerate the same edges and sum them in the same order: every hop's hidden state and the scores are bitwise equal, on
     sparse and saturated hops alike, with hub rows cut into segments (in-degree > 128), lane groups of 4..64, batch sizes
     around the 32-query word, isolated entities, and an automatic pick that matches one of them."""
@@ -422,14 +422,14 @@ def test_word_parallel_walk_bitwise_equals_per_query_walk(d, a, B, n_ent, m):
     outs = {}
     try:
         with torch.no_grad():
-            for walk in (1, 2, 3, 4, 5, 0):
+            for walk in (1, 2, 3, 4, 5, 6, 7, 0):
                 engine.FORCE_WALK = walk
                 trace = []
                 s = model(subs, rels, mode="test", trace=trace)
                 outs[walk] = (s, [x["hidden"].clone() for x in trace])
     finally:
         engine.FORCE_WALK = 0
-    for walk in (2, 3, 4, 5, 0):
+    for walk in (2, 3, 4, 5, 6, 7, 0):
         assert torch.equal(outs[walk][0], outs[1][0]), walk
         for x, y in zip(outs[walk][1], outs[1][1]):
             assert torch.equal(x, y), walk
