@@ -115,7 +115,25 @@ class BaseModel(object):
             p.data.nan_to_num_(nan=np.random.random(), posinf=float("inf"), neginf=float("-inf"))
 
     # ---- filtered evaluation (base_model.py:85-152) ---------------------------------------------------------------
-    EVAL_LANES = 8      # evaluation batches in flight on separate HIP streams (measured on family, n_tbatch = 50: 1 lane 119 k, 2-4 lanes 172 k, 8 lanes 263 k queries/s)
+    # evaluation batches in flight on separate HIP streams, at most (family, n_tbatch = 50: 1 lane 119 k, 2-4 lanes 172 k, 8 lanes 263 k
+    # queries/s in round 2's first version; with the split dense kernel 8 / 12 / 16 lanes: 323 k / 371 k / 430 k).  Every lane holds
+    # its own captured forward with capacity-sized buffers, so large graphs get fewer lanes (WN18RR, 1.7 GB per lane: 8 lanes 112 k
+    # queries/s, 12 lanes 98 k - the lanes' buffers then exceed the replay cache's budget and forwards are re-captured)
+    EVAL_LANES = 16
+
+    def _eval_lanes(self, n_batches):
+        from .models import _GraphedInference, _pad4, pad_attn
+        m = self.model
+        n_ent = max(int(getattr(self.loader, "n_ent", 0)), int(getattr(self.loader, "n_ent_ind", 0)), 1)
+        try:
+            need = _GraphedInference.bytes_needed(self.n_tbatch, n_ent, max(16, _pad4(m.hidden_dim)), pad_attn(m.attn_dim))
+        except (AttributeError, ValueError):        # a model without the replayed forward
+            need = 0
+        fit = self.EVAL_LANES if need <= 0 else int(_GraphedInference.MAX_BYTES // (3 * need // 2 + 1))
+        lanes = min(self.EVAL_LANES, max(8, n_batches // 8))      # (umls, 28 batches: 8 lanes 364 k queries/s, 16 lanes 305 k)
+        while lanes > 1 and lanes > fit:
+            lanes //= 2
+        return max(1, min(lanes, n_batches))
 
     def _rank_split(self, data, n_data):
         """Filtered ranks of a split.  A 50-query batch (the reference's n_tbatch) is a chain of small dependent kernels that
@@ -124,7 +142,7 @@ class BaseModel(object):
         mode = self.loader.eval_mode(data) if hasattr(self.loader, "eval_mode") else data
         device = next(self.model.parameters()).device
         batches = _chunks(n_data, self.n_tbatch)[self.rank::self.world]             # evaluation batches dealt round-robin
-        n_lanes = max(1, min(self.EVAL_LANES, len(batches)))
+        n_lanes = self._eval_lanes(len(batches))
         main = torch.cuda.current_stream(device)
         if n_lanes > 1:
             lanes = self.__dict__.setdefault("_eval_streams", [])

@@ -438,7 +438,7 @@ class RED_GNN_trans(nn.Module):
             # memory budget for the capacity-sized buffers
             need = _GraphedInference.bytes_needed(n, graph.n_ent, ld, ap)
             held = sum(_GraphedInference.bytes_needed(v.n, v.graph.n_ent, v.ld, v.ap) for v in self._graphed.values())
-            if len(self._graphed) >= 32 or held + need > 2 * _GraphedInference.MAX_BYTES:
+            if len(self._graphed) >= 80 or held + need > 2 * _GraphedInference.MAX_BYTES:
                 self._graphed.clear()
             try:
                 g = self._graphed[key] = _GraphedInference(self, graph, n, device, hints)
