@@ -1154,14 +1154,15 @@ def test_dense_kernel_row_count_edges(d, prec, n):
         assert torch.equal(out2, out)
 
 
+@pytest.mark.parametrize("d", [64, 128])
 @pytest.mark.parametrize("scale", [1e-6, 1e-3, 1.0, 300.0])
-def test_split_dense_kernel_fits_its_weight_scale(scale):
+def test_split_dense_kernel_fits_its_weight_scale(scale, d):
     """The f16-split dense kernel stages all weights under one power-of-two scale: 2^12 by default, refitted in a second staging pass
     when the weights' largest magnitude would overflow f16 or leave the lo halves denormal.  Both paths against fp64, at the same
     tolerance as unit-scale weights (relative to each output's magnitude)."""
     from red_gnn_amd import engine
     torch.manual_seed(11)
-    dev, n, d, a, ap = "cuda", 3000, 64, 5, 8
+    dev, n, a, ap = "cuda", 3000, 5, 8
     agg = torch.randn(n, d, device=dev)
     hprev = torch.tanh(torch.randn(n // 2, d, device=dev))
     prev = torch.randint(-1, n // 2, (n,), device=dev, dtype=torch.int32)
