@@ -49,6 +49,9 @@ def test_argument_errors_are_reported_not_fatal():
     assert b"int32" in lib.rg_last_error()
     assert lib.rg_dense_fwd_supported(64, 5) == 1 and lib.rg_dense_fwd_supported(128, 5) == 1
     assert lib.rg_dense_fwd_supported(96, 5) == 0 and lib.rg_dense_fwd_supported(64, 30) == 0
+    # scratch of the dense call: only d = 128 with split products (the weights' split image: 58 blocks of 8 KB + header)
+    assert lib.rg_dense_scratch_bytes(64, 0) == 0 and lib.rg_dense_scratch_bytes(64, 1) == 0 and lib.rg_dense_scratch_bytes(128, 0) == 0
+    assert lib.rg_dense_scratch_bytes(128, 1) == 256 + 58 * 8192
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
