@@ -180,11 +180,11 @@ __global__ __launch_bounds__(FWD_BLOCK, 6) void layer_fwd_kernel(FwdArgs A) {
       const unsigned long long m = (__ballot(valid) >> gshift) & gmask;
       const int cnt = __popcll(m);
       const int pos = __popcll(m & ((1ull << lane_g) - 1ull));
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // previous round's reads are done
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // previous round's reads are done
       __builtin_amdgcn_wave_barrier();
       if (lane_g >= cnt) my_stage[lane_g] = f4zero();          // pad tuples: alpha = 0, row 0
       if (valid) my_stage[pos] = make_float4(__int_as_float(s), __int_as_float(r), alpha, __int_as_float(trow));
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
 
       // ---- phase 2: one edge per group step, 4 row gathers in flight ---------------------------

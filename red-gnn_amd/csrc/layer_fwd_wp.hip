@@ -154,7 +154,7 @@ __global__ __launch_bounds__(WP_BLOCK, 4) void layer_fwd_wp_kernel(WpArgs A) {
         qn += c0 + c1;
         todo &= todo - 1;
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
       // ---- phase 1: queued edges -> tuples, two per lane and trip (their load chains overlap) --------------------------
 #pragma unroll
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(WP_BLOCK, 4) void layer_fwd_wp_kernel(WpArgs A) {
           }
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
       // ---- phase 2: the lane groups take contiguous shares of the queue, cut at destination boundaries, and stream through
       // them one edge per trip with the next edge's row already in flight ---------------------------------------------------
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(WP_BLOCK, 4) void layer_fwd_wp_kernel(WpArgs A) {
           e += 2;
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the queue is read out before the next fill overwrites it
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // the queue is read out before the next fill overwrites it
       __builtin_amdgcn_wave_barrier();
     }
   };

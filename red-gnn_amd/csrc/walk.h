@@ -106,10 +106,10 @@ __device__ __forceinline__ void walk_items(const WalkArgs& A, int4* recs, F&& ru
       const unsigned long long surv = __ballot(ok);
       const int n_surv = __popcll(surv);
       if (n_surv > 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (ok) my_recs[__popcll(surv & ((1ull << lane) - 1ull))] = rec;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         for (int j = 0; j < n_surv; j += GW) {
           const bool live = j + gi_w < n_surv;
