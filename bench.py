@@ -240,6 +240,108 @@ def family_eval(dist, world, engine):
         engine.KERNEL_EVENTS, engine.DENSE_EVENTS = saved
 
 
+def bench_temporal(args, dist, world, rank, engine):
+    """--config C5: BASELINE configs[4], the temporal interpolation path (T_RED_GNN, model_cuda.py layout) on the ICEWS14-shaped synthetic:
+    a step = forward of B (head, relation, time) queries (expansion + 5 fused temporal layers + readout), queries sharded over ranks.
+    The CPU leg is the oracle's temporal_forward on a few of the same queries (scores compared at the fp64-anchored tolerance)."""
+    from red_gnn_amd.synthetic import SHAPES, make_temporal_shape
+    from red_gnn_amd.temporal import T_RED_GNN
+    sh, tkg = SHAPES["C5"], make_temporal_shape("C5", seed=1234)
+    d, n_layer = sh["hidden_dim"], sh["n_layer"]
+
+    class TP:
+        pass
+
+    p = TP()
+    p.n_rel, p.n_ent, p.n_time = tkg.n_rel, tkg.n_ent, tkg.n_time
+    p.hidden_dim, p.attn_dim, p.n_layer, p.act, p.graph, p.device = d, sh["attn_dim"], n_layer, "tanh", tkg.quads, "cuda"
+    torch.manual_seed(1234)
+    model = T_RED_GNN(p, shared_tables=False).cuda().eval()
+    B = args.batch
+    rows = tkg.quads[(np.arange(B * world) % tkg.n_base)[rank::world]]
+    batch = {"head": rows[:, 0], "relation": rows[:, 1], "time": rows[:, 3]}
+    kernel_events = []
+    if not args.no_kernel_events:
+        engine.KERNEL_EVENTS = kernel_events
+
+    def step():
+        with torch.no_grad():
+            return model(batch, mode="test"), model.last_stats
+
+    for _ in range(args.warmup):
+        step()
+    kernel_events.clear()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    edges = 0
+    for _ in range(args.steps):
+        scores, st = step()
+        edges += sum(st["n_edges"])
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt, float(edges)], device="cuda", dtype=torch.float64)
+    if dist is not None:
+        tmax = tt.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = tt.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt, edges = float(tmax[0]), float(tsum[1])
+    if rank != 0:
+        return
+    roof = None
+    ev_ms = [(e0.elapsed_time(e1), ne, nn) for (e0, e1, ne, nn) in kernel_events]
+    if ev_ms:
+        # SURVEY 8(d), temporal: per edge one fp32 row + five int32 (head, rel, tail, time, query time): E (4d + 20) + N 4d
+        ms = sum(m for m, _, _ in ev_ms)
+        nbytes = sum(ne * (4 * d + 20) + nn * 4 * d for _, ne, nn in ev_ms)
+        roof = dict(bound="hbm", kernel="layer_fwd_kernel<TEMPORAL>", achieved=nbytes / (ms * 1e-3) / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s",
+                    frac=nbytes / (ms * 1e-3) / HBM_PEAK, traffic=None, launches=len(ev_ms), avg_launch_ms=ms / len(ev_ms),
+                    algorithmic_bytes_per_launch=nbytes / len(ev_ms),
+                    kernel_edges_per_s=sum(ne for _, ne, _ in ev_ms) / (ms * 1e-3),
+                    note="the kernel gathers three rows per edge (direction-projected state, relation and time rows) and a 32-wide attention "
+                         "row; SURVEY's byte model counts one")
+    cpu = parity = None
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import redgnn_oracle as orc
+        n_s = 4
+        pd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        hb, rb, tb = (batch[k][:n_s] for k in ("head", "relation", "time"))
+        t1 = time.perf_counter()
+        tr = []
+        ref = orc.temporal_forward(pd, tkg.quads, tkg.n_ent, hb, rb, tb, n_layer, "tanh", trace=tr).numpy()
+        t_cpu = time.perf_counter() - t1
+        ref64 = orc.temporal_forward(pd, tkg.quads, tkg.n_ent, hb, rb, tb, n_layer, "tanh", dtype=torch.float64).numpy()
+        got = scores[:n_s].cpu().numpy()
+        e_cpu = sum(t["n_edges"] for t in tr)
+        err_gpu, err_cpu = float(np.abs(got - ref64).max()), float(np.abs(ref - ref64).max())
+        tol_ok = bool(np.all(np.abs(got - ref) <= 2e-5 + 1e-4 * np.abs(ref)) or err_gpu <= 4 * max(err_cpu, 1e-7))
+        parity = dict(parity_at_bench_size=bool(tol_ok and np.array_equal(got == 0, ref == 0)), queries_checked=n_s,
+                      gpu_max_err_vs_fp64=err_gpu, cpu_fp32_max_err_vs_fp64=err_cpu,
+                      note="model_cuda.py layout: checked against the oracle only (parity unpinned, DESIGN 2)")
+        cpu = dict(value=e_cpu / t_cpu, unit="edges/s", cores=torch.get_num_threads(), kind="port",
+                   sample="%d of the batch's queries, oracle temporal_forward, %.1f s" % (n_s, t_cpu))
+    out = {
+        "metric": "edges aggregated/sec + MRR-eval queries/sec, family KG n_layer=3 at 1/2/4/8 GPU",
+        "value": edges / dt, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "C5 ICEWS14-shaped temporal synthetic %d entities / %d relation rows / %d time ids / %d quadruples (seed 1234), "
+                               "interpolation path n_layer=%d hidden_dim=%d attn_dim=%d, step = expansion + fused temporal layers + readout, "
+                               "%d queries per GPU" % (tkg.n_ent, tkg.n_rel, tkg.n_time, sh["n_triples"], n_layer, d, sh["attn_dim"], B),
+                   "batch_per_gpu": B, "global_batch": B * world, "sharding": "queries strided over ranks" if world > 1 else "none"},
+        "eval_queries_per_s": B * world * args.steps / dt, "edges_per_step": edges / args.steps,
+        "roofline": roof, "cpu_baseline": cpu, "parity": parity, "rg_version": int(_lib_version()),
+    }
+    print(json.dumps(out))
+
+
+def _lib_version():
+    from red_gnn_amd import _lib
+    return _lib.lib().rg_version()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -291,6 +393,11 @@ def main():
     from red_gnn_amd.synthetic import SHAPES, make_shape
     from red_gnn_amd.utils import cal_ranks_csr
 
+    if args.config == "C5":          # the temporal interpolation path has its own model and step
+        bench_temporal(args, dist, world, rank, engine)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     shape = SHAPES[args.config]
     kg = make_shape(args.config, seed=1234)
     ids = dict(n_ent=kg.n_ent, n_rel=kg.n_rel, facts=kg.facts, train=kg.train, valid=kg.valid, test=kg.test)

@@ -354,10 +354,17 @@ def tlayer_fwd(frontier, graph, level, n_new, q_time, hidden_dir, rela_dir, time
     agg = torch.empty((n_new, ld), dtype=torch.float32, device=hidden_dir.device)
     nbytes = _lib.lib().rg_layer_fwd_scratch_bytes(frontier.handle, graph.handle, ld)
     scratch = frontier.scratch(nbytes)
+    ev = None
+    if KERNEL_EVENTS is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
     _lib.check(_lib.lib().rg_tlayer_fwd(frontier.handle, graph.handle, level, n_new, _lib.ptr(q_time), _lib.ptr(hidden_dir),
                                         _lib.ptr(rela_dir), _lib.ptr(time_dir), d, ld, _lib.ptr(a_s), _lib.ptr(a_r), _lib.ptr(a_q),
                                         ap, _lib.ptr(w_alpha), _lib.ptr(b_alpha), attn_dim, _lib.ptr(agg), _lib.ptr(scratch),
                                         nbytes, _lib.stream_ptr()))
+    if ev is not None:
+        ev[1].record()
+        KERNEL_EVENTS.append((ev[0], ev[1], frontier.n_edges, n_new))
     return agg
 
 
