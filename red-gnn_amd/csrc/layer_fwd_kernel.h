@@ -75,7 +75,7 @@ __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0
 constexpr int FWD_BLOCK = 512;   // 3 workgroups per CU = 24 waves at <= 80 VGPRs (no spills)
 
 template <int G, int AP4, bool PACKED, bool DENSE, int KPG, bool RELA_LDS, bool TEMPORAL>
-__global__ __launch_bounds__(FWD_BLOCK, TEMPORAL ? (AP4 >= 8 ? 2 : 4) : 6) void layer_fwd_kernel(FwdArgs A) {
+__global__ __launch_bounds__(FWD_BLOCK, TEMPORAL ? (AP4 >= 8 ? 2 : 4) : (G >= 32 ? 4 : 6)) void layer_fwd_kernel(FwdArgs A) {
   extern __shared__ float4 lds[];
   constexpr int BLOCK = FWD_BLOCK;
   float4* stage = lds;                                   // [BLOCK] edge tuples {s, r, alpha, -}
