@@ -117,8 +117,9 @@ class BaseModel(object):
     # ---- filtered evaluation (base_model.py:85-152) ---------------------------------------------------------------
     # evaluation batches in flight on separate HIP streams, at most (family, n_tbatch = 50: 1 lane 119 k, 2-4 lanes 172 k, 8 lanes 263 k
     # queries/s in round 2's first version; with the split dense kernel 8 / 12 / 16 lanes: 323 k / 371 k / 430 k).  Every lane holds
-    # its own captured forward with capacity-sized buffers, so large graphs get fewer lanes (WN18RR, 1.7 GB per lane: 8 lanes 112 k
-    # queries/s, 12 lanes 98 k - the lanes' buffers then exceed the replay cache's budget and forwards are re-captured)
+    # its own captured forward with capacity-sized buffers (WN18RR: 1.7 GB per lane and batch shape), so the lane count also follows
+    # the replay cache's budget (WN18RR 8 / 12 / 16 / 24 lanes: 93 k / 111 k / 105 k / 105 k queries/s under a 96 GB budget; with
+    # 24 GB the lanes' buffers evicted each other and 12 lanes lost to 8)
     EVAL_LANES = 16
 
     def _eval_lanes(self, n_batches):

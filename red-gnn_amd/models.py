@@ -225,7 +225,7 @@ class _GraphedInference:
     kernels take the level's size from device memory (rg_dense_fwd_dev) or do not need it (bitmap walk), and the sequence is
     captured once and replayed: one graph launch per batch, nothing synchronises."""
 
-    MAX_BYTES = 24 << 30
+    MAX_BYTES = 64 << 30      # of the 288 GB: capacity-sized replay buffers of all lanes and batch shapes together may take twice this
 
     def __init__(self, model, graph, n, device, hints):
         self.model, self.graph, self.n, self.hints = model, graph, n, hints

@@ -1,0 +1,28 @@
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, "/root/repo")
+from red_gnn_amd.base_model import BaseModel
+from red_gnn_amd.load_data import DataLoader
+from red_gnn_amd import models
+from train import PRESETS
+root = "/root/repo/tests/golden"
+name = "WN18RR"
+loader = DataLoader(ids=dict(np.load(os.path.join(root, name + "_ids.npz"))), verbose=False)
+class Opt:
+    lr, decay_rate, lamb, hidden_dim, attn_dim, n_layer, dropout, act, n_batch, n_tbatch = PRESETS[name]
+    n_rel = loader.n_rel
+for budget, lanes in ((24, 8), (96, 16), (96, 12), (96, 24)):
+    models._GraphedInference.MAX_BYTES = budget << 30
+    BaseModel.EVAL_LANES = lanes
+    np.random.seed(1234); torch.manual_seed(1234)
+    bm = BaseModel(Opt, loader)
+    for _ in range(4):
+        bm.evaluate()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(3):
+        mrr, out = bm.evaluate()
+    torch.cuda.synchronize(); t = (time.perf_counter() - t0) / 3
+    nq = loader.n_valid + loader.n_test
+    print(name, "budget GB", budget, "lanes cap", lanes, "used", bm._eval_lanes(10 ** 6), "%.0f queries/s" % (nq / t), "mem GB %.1f" % (torch.cuda.max_memory_allocated() / 2**30), flush=True)
+    del bm
+    torch.cuda.empty_cache()
