@@ -1,0 +1,31 @@
+"""Family evaluation (n_tbatch = 50) with the layer walk forced: 0 = the library's pick, 1 = per-query walk, 2..5 = word-parallel."""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from red_gnn_amd import engine
+from red_gnn_amd.base_model import BaseModel
+from red_gnn_amd.load_data import DataLoader
+
+ids = dict(np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "family_ids.npz")))
+loader = DataLoader(ids=ids, verbose=False)
+for walk in (0, 1, 4, 5, 0):
+    class Opt:
+        lr, decay_rate, lamb, hidden_dim, attn_dim, n_layer, dropout, act, n_batch, n_tbatch = 0.0036, 0.999, 1.7e-5, 64, 5, 3, 0.29, "relu", 20, 50
+        n_rel = loader.n_rel
+    torch.manual_seed(1234)
+    engine.FORCE_WALK = walk
+    bm = BaseModel(Opt, loader)
+    if walk:      # a forced walk overrides the recorded per-hop plan of the replayed forwards
+        orig = engine.layer_fwd_plan
+        engine.layer_fwd_plan = lambda *a, **k: walk
+    for _ in range(4):
+        bm.evaluate()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(4):
+        mrr, out = bm.evaluate()
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 4
+    if walk:
+        engine.layer_fwd_plan = orig
+    nq = loader.n_valid + loader.n_test
+    print("walk %d: %.0f queries/s  mrr %.4f" % (walk, nq / dt, mrr), flush=True)
+engine.FORCE_WALK = 0
