@@ -100,6 +100,9 @@ int rg_frontier_expand_async(rg_frontier* f, const rg_graph* g, void* stream);
  * call: for small batches (batch * ceil(n_ent/32) <= 12288 words) the level build and the node list are ONE single-workgroup launch
  * instead of six, which is what a replayed graph at the reference's n_tbatch = 50 is made of (launch latency, not work). */
 int rg_frontier_expand_nodes_async(rg_frontier* f, const rg_graph* g, int32_t* nodes_out, int32_t* prev_idx_out, void* stream);
+/* After an asynchronous expansion the hop's edge count is not known on the host; a caller that knows what to expect (from an eager run of
+ * the same shape) says so: it only tunes the work distribution of the next rg_layer_fwd (any value is correct).  Cleared by the next expansion. */
+int rg_frontier_set_edge_hint(rg_frontier* f, int64_t n_edges);
 const int32_t* rg_frontier_count_ptr(const rg_frontier* f);
 int rg_frontier_level_counts(const rg_frontier* f, int64_t* counts_host, void* stream);
 /* nodes of the current level: nodes_out int32 [N_new,2] = (batch, entity) sorted

@@ -16,7 +16,7 @@ SYMBOLS = [
     "rg_frontier_workspace_bytes", "rg_frontier_create", "rg_frontier_destroy", "rg_frontier_reset",
     "rg_frontier_reset_nodes", "rg_frontier_expand", "rg_frontier_nodes", "rg_frontier_edges_scratch_bytes", "rg_frontier_edges",
     "rg_layer_fwd_scratch_bytes", "rg_layer_fwd", "rg_layer_fwd_plan", "rg_tlayer_fwd", "rg_xlayer_fwd", "rg_frontier_set_window", "rg_layer_bwd_scratch_bytes", "rg_layer_bwd", "rg_tlayer_bwd_scratch_bytes", "rg_tlayer_bwd", "rg_dense_fwd_supported", "rg_dense_scratch_bytes", "rg_dense_fwd", "rg_dense_fwd_dev", "rg_dense_train_fwd", "rg_dense_train_bwd", "rg_rank",
-    "rg_frontier_expand_async", "rg_frontier_expand_nodes_async", "rg_frontier_count_ptr", "rg_frontier_level_counts", "rg_attn_tables",
+    "rg_frontier_expand_async", "rg_frontier_expand_nodes_async", "rg_frontier_set_edge_hint", "rg_frontier_count_ptr", "rg_frontier_level_counts", "rg_attn_tables",
 ]
 
 _lib = None
@@ -61,6 +61,7 @@ def lib():
     L.rg_frontier_expand.argtypes = [vp, vp, C.POINTER(i64), vp]
     L.rg_frontier_expand_async.argtypes = [vp, vp, vp]
     L.rg_frontier_expand_nodes_async.argtypes = [vp, vp, vp, vp, vp]
+    L.rg_frontier_set_edge_hint.argtypes = [vp, i64]
     L.rg_attn_tables.argtypes = [i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.rg_frontier_count_ptr.argtypes = [vp]
     L.rg_frontier_count_ptr.restype = vp

@@ -150,5 +150,6 @@ struct rg_frontier {
   int tcur = 0;                      // which bitsT holds the newest level
   int64_t n_nodes[RG_MAX_LEVELS] = {};  // per slot
   int64_t n_edges = 0;
+  int64_t edge_hint = -1;            // the caller's expectation of n_edges while it is unknown on the host (after rg_frontier_expand_async)
   const int2* bm_of(int lvl) const { return bm[lvl % n_levels]; }
 };

@@ -541,6 +541,13 @@ int rg_frontier_expand_nodes_async(rg_frontier* f, const rg_graph* g, int32_t* n
   if (enqueue_expand(f, g, (hipStream_t)stream, nodes_out, prev_idx_out)) return 1;
   f->n_nodes[f->level % f->n_levels] = -1;      // unknown on the host: the layer calls take their n as a capacity hint
   f->n_edges = -1;
+  f->edge_hint = -1;
+  return 0;
+}
+
+int rg_frontier_set_edge_hint(rg_frontier* f, int64_t n_edges) {
+  RG_CHECK(f != nullptr, "rg_frontier_set_edge_hint: NULL frontier");
+  f->edge_hint = n_edges;
   return 0;
 }
 

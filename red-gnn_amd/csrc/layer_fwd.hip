@@ -79,7 +79,7 @@ extern "C" int rg_layer_fwd(const rg_frontier* f, const rg_graph* g, int32_t lev
     W.w_alpha = w_alpha; W.b_alpha = b_alpha; W.attn_dim = attn_dim; W.n_rela_rows = g->n_rela_rows;
     W.agg = A.agg; W.partial = A.partial; W.queues = f->queues; W.queues_clean = A.walk.queues_clean;
     // a ticket is a returning atomic: about 200 edges' worth of items each (light items: hop 0; heavy ones are taken one by one)
-    const int64_t n_e = level == f->level ? f->n_edges : -1;
+    const int64_t n_e = level == f->level ? (f->n_edges >= 0 ? f->n_edges : f->edge_hint) : -1;
     const int64_t by_work = n_e < 0 ? 2 : 200 * W.n_items / std::max<int64_t>(n_e, 1);
     W.ipt = (int32_t)std::max<int64_t>(std::min<int64_t>(std::min<int64_t>(by_work, W.n_items / 8192), 32), 1);   // ... and never fewer tickets than waves
     const size_t n_part = (size_t)f->B * g->in_vr.n_slots;

@@ -182,9 +182,11 @@ class Frontier:
         self.level += 1
         self.n_new = self.n_old = self.n_edges = -1
 
-    def expand_nodes_async(self, graph, nodes, prev):
+    def expand_nodes_async(self, graph, nodes, prev, edge_hint=None):
         """expand_async + nodes_into in one library call (rg_frontier_expand_nodes_async: one fused launch for small batches)."""
         _lib.check(_lib.lib().rg_frontier_expand_nodes_async(self.handle, graph.handle, _lib.ptr(nodes), _lib.ptr(prev), _lib.stream_ptr()))
+        if edge_hint is not None and edge_hint >= 0:      # what an eager run of the same shape counted: tunes the next layer call's tickets
+            _lib.check(_lib.lib().rg_frontier_set_edge_hint(self.handle, int(edge_hint)))
         self.level += 1
         self.n_new = self.n_old = self.n_edges = -1
 

@@ -278,9 +278,9 @@ class _GraphedInference:
         tables = m.inference_tables(self.q_rel, ld, ap)
         for i in range(m.n_layer):
             layer = m.gnn_layers[i]
-            fr.expand_nodes_async(graph, self.nodes, self.prev)
+            n_hint, walk, e_hint = (tuple(self.hints[i]) + (None,))[:3]
+            fr.expand_nodes_async(graph, self.nodes, self.prev, edge_hint=e_hint)
             a_r, a_q, rela_p = tables[i]
-            n_hint, walk = self.hints[i]
             engine.layer_fwd_into(fr, graph, fr.level, n_hint, hidden, rela_p, d, a_s, a_r, a_q,
                                   layer.w_alpha.weight.reshape(-1).contiguous(), layer.w_alpha.bias, a, self.agg, self.scratch, walk=walk)
             last = i + 1 == m.n_layer
@@ -431,7 +431,7 @@ class RED_GNN_trans(nn.Module):
             if seen < 2 or _GraphedInference.bytes_needed(n, graph.n_ent, ld, ap) > _GraphedInference.MAX_BYTES:
                 self._pending_key = key          # the eager run that follows records its per-hop sizes under this key
                 return None
-            hints = self._hints.get(key) or [(n * graph.n_ent, 1)] * self.n_layer      # (node count, walk) per hop
+            hints = self._hints.get(key) or [(n * graph.n_ent, 1, None)] * self.n_layer      # (node count, walk, edge count) per hop
             if key in self._graph_failed:
                 return None
             # a split's evaluation uses a few shapes (the batch size and the last, partial batches): keep them all, within a
@@ -469,7 +469,7 @@ class RED_GNN_trans(nn.Module):
             n_new, n_e, n_old = fr.expand(graph)
             nodes, prev_idx, old_new = fr.nodes(want_prev=True, want_old_new=trace is not None)
             n_edges.append(n_e)
-            sizes.append((n_new, engine.layer_fwd_plan(fr, graph, fr.level, n_old, n_new, n_e, ld)))
+            sizes.append((n_new, engine.layer_fwd_plan(fr, graph, fr.level, n_old, n_new, n_e, ld), n_e))
             layer = self.gnn_layers[i]
             agg = layer.aggregate_nograd(tables[i], hidden, a_s, fr, graph, fr.level, nodes)
             last = i + 1 == self.n_layer
