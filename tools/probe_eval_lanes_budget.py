@@ -1,11 +1,12 @@
 import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, "/root/repo")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 from red_gnn_amd.base_model import BaseModel
 from red_gnn_amd.load_data import DataLoader
 from red_gnn_amd import models
 from train import PRESETS
-root = "/root/repo/tests/golden"
+root = os.path.join(ROOT, "tests", "golden")
 name = "WN18RR"
 loader = DataLoader(ids=dict(np.load(os.path.join(root, name + "_ids.npz"))), verbose=False)
 class Opt:

@@ -1,9 +1,10 @@
 import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, "/root/repo")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 from red_gnn_amd.base_model import BaseModel
 from red_gnn_amd.load_data import DataLoader
-ids = dict(np.load("/root/repo/tests/golden/family_ids.npz"))
+ids = dict(np.load(os.path.join(ROOT, "tests", "golden", "family_ids.npz")))
 loader = DataLoader(ids=ids, verbose=False)
 class Opt:
     lr, decay_rate, lamb, hidden_dim, attn_dim, n_layer, dropout, act, n_batch, n_tbatch = 0.0036, 0.999, 1.7e-5, 64, 5, 3, 0.29, "relu", 20, 50
