@@ -205,6 +205,42 @@ def test_forward_vs_oracle_c2_shape_small_batch():
     np.testing.assert_allclose(s, ref, rtol=RTOL, atol=2e-5)
 
 
+@pytest.mark.parametrize("B", [3, 6, 40, 400])
+def test_level_build_paths_give_the_reference_node_lists(B):
+    """The ways a new level's node list is built - one workgroup with its node list fused (B x ceil(n_ent / 32) <= 1 024 words) or as
+    a launch of its own (<= 9 216 words), the general multi-launch transpose + scan + pack - against a dense numpy expansion on C2
+    (313 words per query: 3 / 6 / 40 and 400 queries): node lists in (query, entity) order, links to the previous level, and the edge
+    count of every hop."""
+    from red_gnn_amd import engine
+    _, kg, ids, loader = _shape_loader("C2")
+    g = loader.graph_for("test")
+    rng = np.random.default_rng(B)
+    heads = rng.integers(0, kg.n_ent, B).astype(np.int32)
+    trip = np.concatenate([kg.facts, kg.train], 0)
+    src = np.concatenate([trip[:, 0], trip[:, 2], np.arange(kg.n_ent)])      # facts, inverses, self loops
+    dst = np.concatenate([trip[:, 2], trip[:, 0], np.arange(kg.n_ent)])
+    outdeg = np.bincount(src, minlength=kg.n_ent)
+    adj = np.zeros((kg.n_ent, kg.n_ent), dtype=bool)
+    adj[src, dst] = True
+    fr = engine.Frontier(kg.n_ent, B, 2, "cuda")
+    fr.reset(torch.as_tensor(heads, device="cuda"))
+    cur = np.zeros((B, kg.n_ent), dtype=bool)
+    cur[np.arange(B), heads] = True
+    for hop in range(3):
+        n_new, n_e, n_old = fr.expand(g)
+        nodes, prev_idx, _ = fr.nodes(want_prev=True, want_old_new=False)
+        nxt = (cur.astype(np.float32) @ adj.astype(np.float32)) > 0
+        want = np.argwhere(nxt)
+        assert n_new == len(want) and n_old == int(cur.sum())
+        assert n_e == int((cur * outdeg[None, :]).sum())
+        assert np.array_equal(nodes.cpu().numpy(), want)
+        old = np.argwhere(cur)
+        rank_old = -np.ones((B, kg.n_ent), dtype=np.int64)
+        rank_old[old[:, 0], old[:, 1]] = np.arange(len(old))
+        assert np.array_equal(prev_idx.cpu().numpy(), rank_old[want[:, 0], want[:, 1]])
+        cur = nxt
+
+
 def _shape_loader(cfg):
     from red_gnn_amd.load_data import DataLoader
     from red_gnn_amd.synthetic import SHAPES, make_shape
