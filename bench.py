@@ -12,9 +12,13 @@ whose oracle scores double as an end-to-end parity check at bench size.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--no-cpu-baseline] [--no-family-eval]
 
+    python bench.py --train [--config C2] [--batch 256]        one training step (forward + loss + HIP backward + Adam) per step
+    python bench.py --global-batch G --gpus N                  strong scaling: G queries dealt over the N ranks (BASELINE's C4 256 / 4)
+
 Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` for the dominant
-kernel (the layer_fwd kernels, HIP events on their stream), `roofline_l2` (the roof that binds them once a
-query's rows are L2-resident), `per_hop`, `roofline_dense` and `cpu_baseline` (the oracle on host cores).
+kernel (the layer_fwd kernels, HIP events on their stream: the L2-gather roof that binds them, SURVEY 8d's
+algorithmic-HBM figure beside it as `hbm_algorithmic`), `per_hop`, `roofline_dense`, `cpu_baseline` (the oracle on
+host cores) and `family_eval` (configs[0]: real family graph, queries/s, edges/s and its own CPU leg).
 """
 import argparse
 import json
@@ -35,6 +39,17 @@ MFMA_F32_PEAK = 157.3e12   # FLOP/s, same guide: f32-input MFMA = the FP32 vecto
 MFMA_F16_PEAK = 2.5e15     # FLOP/s, same guide: dense f16 / bf16 MFMA
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic_layer_fwd.json")
 
+# `dtype` of the line = the arithmetic the path computes in (storage, sums and - for f32 / f16x3 - operands and products are fp32)
+DTYPE_OF = {"f32": "f32", "f16x3": "f32", "f16x2": "f32 storage and accumulation, dense products on 22-bit operands (f16x2 splits)"}
+DENSE_NOTE = {
+    "f32": "f32: dense products on v_mfma_f32_16x16x4_f32",
+    "f16x3": "f16x3: fp32 arithmetic on the f16 matrix pipe - every fp32 operand carried EXACTLY as hi + mid + lo f16 (33 >= 24 bits; "
+             "bit-exact reconstruction and product tests in tests/test_gpu_parity.py), the six partial products of order >= 2^-22 per "
+             "product (error <= 2^-31), fp32 accumulation; dense_f32 = the same step on the f32 MFMA forms",
+    "f16x2": "f16x2 (opt-in): fp32 operands as two-term f16 splits (22 bits), fp32 accumulation; narrower than the reference's fp32 "
+             "nn.Linear / nn.GRU; dense_f32 = the same step on the f32 MFMA forms",
+}
+
 
 class Params:
     def __init__(self, shape, n_rel):
@@ -47,14 +62,24 @@ def algorithmic_bytes(n_edges, n_nodes, d):
     return n_edges * (4 * d + 16) + n_nodes * 4 * d
 
 
+def dense_kernel_of(d, precision):
+    """(kernel name, arithmetic) rg_dense_fwd runs for this width and precision (csrc/dense.hip dispatch)."""
+    if precision == "f16x2":
+        return ("dense_split_kernel" if d <= 64 else "dense128_split_kernel"), "f16x2"
+    if precision == "f16x3" and d <= 64:
+        return "dense_split3_kernel", "f16x3"
+    return ("dense_kernel" if d <= 64 else "dense128_kernel"), "f32"       # f32, and f16x3 at d = 128
+
+
 def dense_roofline(dense_ms, d, attn_dim, n_layer, batch, precision):
     """Second kernel of the step (W_h + act + GRU + projections + readout, rg_dense_fwd), from its launches' HIP events.
     Useful flops per node row (what the reference computes): 2 d d (1 + 3 + 3) for W_h, weight_ih, weight_hh + 2 d attn_dim for the
     hoisted Ws_attn.  Algorithmic bytes per launch: every row's agg in and new state out (8 d), prev_idx (4), a_s out (4 attn_dim
     padded to 4 floats) and one old-state row per node of the previous level (4 d).
-    precision "f32": products on v_mfma_f32_16x16x4_f32 - the matrix pipe bounds the kernel, peak 157.3 TFLOP/s.
-    precision "f16x2": each product is three f16 MFMAs on two-term splits - the matrix pipe is issued 3x the useful flops at 16x the
-    rate and no longer binds; the kernel is priced against HBM by its rows, with the issued f16 rate beside it."""
+    "f32": products on v_mfma_f32_16x16x4_f32 - the f32 matrix pipe bounds the kernel, peak 157.3 TFLOP/s.
+    "f16x3" (d <= 64): fp32 arithmetic as exact three-term f16 splits - six f16 / bf8 MFMAs per product: the f16 matrix pipe is issued
+    6x the useful flops and is the roof that binds (2.5 PFLOP/s dense); the HBM fraction by the kernel's rows is kept beside it.
+    "f16x2" (opt-in, 22-bit operands): three MFMAs per product; priced against HBM by its rows, with the issued f16 rate beside it."""
     ms = sum(m for m, _ in dense_ms)
     rows = sum(n for _, n in dense_ms)
     flops = rows * (2.0 * d * d * 7 + 2.0 * d * attn_dim)
@@ -63,19 +88,22 @@ def dense_roofline(dense_ms, d, attn_dim, n_layer, batch, precision):
     for i, (_, n) in enumerate(dense_ms):
         n_old = batch if i % n_layer == 0 else dense_ms[i - 1][1]
         nbytes += n * (8.0 * d + 4 + 4 * ap) + n_old * 4.0 * d
+    kernel, arith = dense_kernel_of(d, precision)
+    t = ms * 1e-3
     common = dict(launches=len(dense_ms), avg_launch_ms=ms / len(dense_ms), algorithmic_flops_per_launch=flops / len(dense_ms),
-                  algorithmic_bytes_per_launch=nbytes / len(dense_ms), useful_tflops=flops / (ms * 1e-3) / 1e12, precision=precision,
-                  traffic=None)
-    if precision == "f32":
-        return dict(bound="mfma", kernel="dense_kernel" if d <= 64 else "dense128_kernel", achieved=flops / (ms * 1e-3) / 1e12,
-                    peak=MFMA_F32_PEAK / 1e12, unit="TFLOP/s",
-                    frac=flops / (ms * 1e-3) / MFMA_F32_PEAK, **common)
-    return dict(bound="hbm", kernel="dense_split_kernel" if d <= 64 else "dense128_split_kernel", achieved=nbytes / (ms * 1e-3) / 1e9,
-                peak=HBM_PEAK / 1e9, unit="GB/s",
-                frac=nbytes / (ms * 1e-3) / HBM_PEAK,
-                mfma=dict(issued_f16_tflops=3 * flops / (ms * 1e-3) / 1e12, peak=MFMA_F16_PEAK / 1e12,
-                          frac=3 * flops / (ms * 1e-3) / MFMA_F16_PEAK, useful_over_f32_mfma_peak=flops / (ms * 1e-3) / MFMA_F32_PEAK),
-                **common)
+                  algorithmic_bytes_per_launch=nbytes / len(dense_ms), useful_tflops=flops / t / 1e12, precision=arith,
+                  hbm_algorithmic_frac=nbytes / t / HBM_PEAK, traffic=None)
+    if arith == "f32":
+        return dict(bound="mfma", kernel=kernel, achieved=flops / t / 1e12, peak=MFMA_F32_PEAK / 1e12, unit="TFLOP/s",
+                    frac=flops / t / MFMA_F32_PEAK, **common)
+    n_mfma = 6 if arith == "f16x3" else 3
+    mfma = dict(issued_f16_tflops=n_mfma * flops / t / 1e12, peak=MFMA_F16_PEAK / 1e12, frac=n_mfma * flops / t / MFMA_F16_PEAK,
+                useful_over_f32_mfma_peak=flops / t / MFMA_F32_PEAK)
+    if arith == "f16x3":
+        return dict(bound="mfma", kernel=kernel, achieved=mfma["issued_f16_tflops"], peak=mfma["peak"], unit="TFLOP/s", frac=mfma["frac"],
+                    mfma=mfma, **common)
+    return dict(bound="hbm", kernel=kernel, achieved=nbytes / t / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", frac=nbytes / t / HBM_PEAK,
+                mfma=mfma, **common)
 
 
 def stored_traffic(config, batch, version, path=TRAFFIC_FILE):
@@ -93,32 +121,40 @@ def stored_traffic(config, batch, version, path=TRAFFIC_FILE):
 
 
 def layer_rooflines(events_ms, d, n_layer, traffic_entry=None):
-    """The roofline objects of the message-passing kernel from per-launch records (ms, n_edges, n_nodes), launch i being hop
+    """The roofline object of the message-passing kernel from per-launch records (ms, n_edges, n_nodes), launch i being hop
     i % n_layer.  Pure arithmetic (tested on the host).
 
-    roofline     the contract's object: ALGORITHMIC bytes (every gathered row counted as if it came from HBM) over
-                 the measured launch time against the HBM peak.  Its frac can exceed 1 because the rows are not HBM traffic.
-    roofline_l2  the roof that binds: gathered row bytes (E * 4d) over the same time against the L2 gather rate; frac <= 1.
+    roofline     the roof that binds: a query's hidden slab is resident in its XCD's L2, so the gathered source rows (E * 4d bytes)
+                 over the measured launch time are priced against the L2 gather rate (MI355X_MICROARCH.md, "Indexed rows": 18.8 TB/s
+                 chip-wide); frac <= 1.  Beside it:
+      hbm_algorithmic   SURVEY 8d's figure: ALGORITHMIC bytes (every gathered row counted as if it came from HBM) over the same time
+                        against the HBM peak - above 1 whenever the rows are served on chip;
+      traffic           HBM bytes per launch measured by the PMC passes (or null), hbm_measured_frac = that over time and HBM peak;
+      l2_request_bytes  (TCC_HIT + TCC_MISS) x 128 B per launch from the same passes: proof that the rows are touched.
     per_hop      E, N, ms, both fractions per hop (expanding hops sit far below saturated ones)."""
     n = len(events_ms)
     if n == 0:
-        return None, None, None
+        return None, None
     tot_ms = sum(ms for ms, _, _ in events_ms)
+    t = tot_ms * 1e-3
     k_bytes = sum(algorithmic_bytes(ne, nn, d) for _, ne, nn in events_ms)
     k_edges = sum(ne for _, ne, _ in events_ms)
-    achieved = k_bytes / (tot_ms * 1e-3)
+    row_bytes = k_edges * 4.0 * d
     traffic = traffic_entry["hbm_bytes_per_launch"] if traffic_entry else None
-    roof = dict(bound="hbm", kernel="layer_fwd kernels (walk + word-parallel)", achieved=achieved / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s",
-                frac=achieved / HBM_PEAK, traffic=traffic, launches=n, avg_launch_ms=tot_ms / n,
-                algorithmic_bytes_per_launch=k_bytes / n, kernel_edges_per_s=k_edges / (tot_ms * 1e-3),
-                note="algorithmic bytes count every gathered row as HBM (SURVEY 8d); a query's rows are L2-resident, so see roofline_l2 "
-                     "for the roof that binds and `traffic` / hbm_measured_frac for the bytes that reach memory")
+    roof = dict(bound="l2-gather", kernel="layer_fwd kernels (walk + word-parallel)", achieved=row_bytes / t / 1e9, peak=L2_GATHER_PEAK / 1e9,
+                unit="GB/s", frac=row_bytes / t / L2_GATHER_PEAK, traffic=traffic, launches=n, avg_launch_ms=tot_ms / n,
+                bytes="gathered source rows: E * 4 * d per launch", row_bytes_per_launch=row_bytes / n,
+                kernel_edges_per_s=k_edges / t,
+                hbm_algorithmic=dict(achieved=k_bytes / t / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", frac=k_bytes / t / HBM_PEAK,
+                                     bytes_per_launch=k_bytes / n,
+                                     note="SURVEY 8d: E (4d + 16) + N 4d, every gathered row counted as HBM; a query's rows are "
+                                          "L2-resident, so this exceeds the HBM peak on saturated hops"))
     if traffic is not None:
         roof["hbm_measured_frac"] = traffic / (tot_ms / n * 1e-3) / HBM_PEAK
         roof["traffic_source"] = traffic_entry.get("source")
-    row_bytes = k_edges * 4.0 * d
-    l2 = dict(bound="l2-gather", kernel=roof["kernel"], achieved=row_bytes / (tot_ms * 1e-3) / 1e9, peak=L2_GATHER_PEAK / 1e9, unit="GB/s",
-              frac=row_bytes / (tot_ms * 1e-3) / L2_GATHER_PEAK, bytes="gathered source rows only: E * 4 * d")
+        req = sum(sum(k.get("TCC_HIT_sum", [])) + sum(k.get("TCC_MISS_sum", [])) for k in traffic_entry.get("per_kernel", {}).values())
+        if req:
+            roof["l2_request_bytes"] = req * 128.0 / n_layer
     hops = []
     for h in range(n_layer):
         sel = events_ms[h::n_layer]
@@ -130,7 +166,7 @@ def layer_rooflines(events_ms, d, n_layer, traffic_entry=None):
         hops.append(dict(hop=h, edges=ne, nodes=nn, ms=ms, edges_per_s=ne / (ms * 1e-3),
                          hbm_algorithmic_frac=algorithmic_bytes(ne, nn, d) / (ms * 1e-3) / HBM_PEAK,
                          l2_gather_frac=ne * 4.0 * d / (ms * 1e-3) / L2_GATHER_PEAK))
-    return roof, l2, hops
+    return roof, hops
 
 
 def cpu_baseline(kg, shape, state, subs, rels, ans, filt, gpu_scores, gpu_ranks, ans_ptr, budget_s=20.0, bs=50):
@@ -191,28 +227,33 @@ def cpu_baseline(kg, shape, state, subs, rels, ans, filt, gpu_scores, gpu_ranks,
          "ranks_identical_to_cpu_path": "%d of %d" % (n_rank_same, n_rank)}
 
 
-def family_eval(dist, world, engine):
-    """BaseModel.evaluate (forward + filtered ranking, valid + test) on the real family graph with the reference's shape for
-    BASELINE configs[0] (n_layer=3, hidden_dim=64, n_tbatch=50) and random-init weights: total queries per second over all
-    ranks (evaluation batches are dealt round-robin).  The id triples are the committed fixture of the reference's data/family."""
+def family_eval(dist, world, engine, cpu_leg=True, rank=0):
+    """BASELINE configs[0]: BaseModel.evaluate (forward + filtered ranking, valid + test) on the real family graph with the reference's
+    shape (n_layer=3, hidden_dim=64, n_tbatch=50) and random-init weights: queries per second and aggregated edges per second over all
+    ranks (evaluation batches are dealt round-robin), and - on rank 0 at N = 1 - the CPU leg of the same configuration: the oracle on
+    the first two test batches (forward + cal_ranks) with score and rank parity against the GPU on those 100 queries.  The id triples
+    are the committed fixture of the reference's data/family."""
     path = os.path.join(ROOT, "tests", "golden", "family_ids.npz")
     if not os.path.exists(path):
         return None
-    from red_gnn_amd.base_model import BaseModel
+    from red_gnn_amd.base_model import BaseModel, _chunks
     from red_gnn_amd.load_data import DataLoader
     saved = engine.KERNEL_EVENTS, engine.DENSE_EVENTS
     engine.KERNEL_EVENTS = engine.DENSE_EVENTS = None          # graph replay path
     try:
-        loader = DataLoader(ids=dict(np.load(path)), verbose=False)
+        ids = dict(np.load(path))
+        loader = DataLoader(ids=ids, verbose=False)
         nq = loader.n_valid + loader.n_test
 
-        def measure(n_tb, reps):
+        def build(n_tb):
             class Opt:
                 lr, decay_rate, lamb, hidden_dim, attn_dim, n_layer, dropout, act, n_batch, n_tbatch = 0.0036, 0.999, 1.7e-5, 64, 5, 3, 0.29, "relu", 20, n_tb
                 n_rel = loader.n_rel
 
             torch.manual_seed(1234)
-            bm = BaseModel(Opt, loader, dist=dist if world > 1 else None)
+            return BaseModel(Opt, loader, dist=dist if world > 1 else None)
+
+        def measure(bm, reps):
             for _ in range(3):                                      # the third pass of a batch shape captures its graph
                 bm.evaluate()
             if dist is not None:
@@ -231,16 +272,80 @@ def family_eval(dist, world, engine):
                 dt = float(t[0])
             return nq * reps / dt, dt / reps, float(mrr)
 
-        qps, per_pass, mrr = measure(50, 5)
-        qps_500, _, mrr_500 = measure(500, 5)         # the same evaluation in batches of 500 (not the reference's setting: for scale only)
-        return dict(queries_per_s=qps, queries=nq, n_tbatch=50, hidden_dim=64, n_layer=3, seconds_per_pass=per_pass,
-                    valid_mrr_of_random_init=mrr, path="HIP graph replay per batch, batches dealt to concurrent streams",
-                    queries_per_s_at_n_tbatch_500=qps_500, same_mrr_at_n_tbatch_500=abs(mrr - mrr_500) < 1e-9)
+        bm = build(50)
+        qps, per_pass, mrr = measure(bm, 5)
+        # edges of one pass (every rank's batches; untimed: one size read-back per batch)
+        edges = 0
+        bm.model.eval()
+        with torch.no_grad():
+            for data, n_data in (("valid", loader.n_valid), ("test", loader.n_test)):
+                for idx in _chunks(n_data, 50)[bm.rank::bm.world]:
+                    subs, rels = loader.get_batch_csr(idx, data=data)[:2]
+                    bm.model(subs, rels, mode=data)
+                    edges += sum(bm.model.last_stats["n_edges"])
+        if dist is not None:
+            t = torch.tensor([float(edges)], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            edges = float(t[0])
+        out = dict(queries_per_s=qps, edges_per_s=edges / per_pass, edges_per_pass=float(edges), queries=nq, n_tbatch=50, hidden_dim=64, n_layer=3,
+                   seconds_per_pass=per_pass, valid_mrr_of_random_init=mrr,
+                   path="HIP graph replay per batch, batches dealt to concurrent streams", dense_precision=bm.model.dense_precision)
+        if cpu_leg and world == 1 and rank == 0:
+            out["cpu_baseline"], out["parity"] = family_cpu_leg(bm, loader, ids)
+            out["speedup_vs_cpu_edges_per_s"] = out["edges_per_s"] / out["cpu_baseline"]["value"]
+        qps_500, _, mrr_500 = measure(build(500), 5)      # the same evaluation in batches of 500 (not the reference's setting: for scale only)
+        out.update(queries_per_s_at_n_tbatch_500=qps_500, same_mrr_at_n_tbatch_500=abs(mrr - mrr_500) < 1e-9)
+        return out
     finally:
         engine.KERNEL_EVENTS, engine.DENSE_EVENTS = saved
 
 
-def bench_temporal(args, dist, world, rank, engine):
+def family_cpu_leg(bm, loader, ids, n_batches=2, bs=50):
+    """The oracle on the family evaluation graph: the first `n_batches` test batches of 50 (forward + cal_ranks, host cores), and the
+    GPU's scores / ranks of the same queries against it (rtol 1e-4 / atol 2e-5 on scores, ranks equal)."""
+    from oracle import redgnn_oracle as orc
+    from red_gnn_amd.utils import cal_ranks_csr
+    n_cpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(max(1, min(n_cpu, 64)))
+    n_ent, n_rel = int(ids["n_ent"]), int(ids["n_rel"])
+    og = orc.OracleGraph(np.concatenate([orc.double_triple(ids["facts"], n_rel), orc.double_triple(ids["train"], n_rel)], 0), n_ent, n_rel)
+    p = {k: v.detach().cpu() for k, v in bm.model.state_dict().items()}
+    t_tot, edges, n_rank, n_same, n_viol, max_err, zero_ok, done = 0.0, 0, 0, 0, 0, 0.0, True, 0
+    bm.model.eval()
+    for b in range(n_batches):
+        idx = np.arange(b * bs, min((b + 1) * bs, loader.n_test))
+        if len(idx) == 0:
+            break
+        subs, rels, a_ptr, a_idx, f_ptr, f_idx = loader.get_batch_csr(idx, data="test")
+        with torch.no_grad():
+            g = bm.model(subs, rels, mode="test")
+            g_ranks = cal_ranks_csr(g, a_ptr, a_idx, f_ptr, f_idx).double().cpu().numpy()
+        g = g.cpu().numpy()
+        t0 = time.perf_counter()
+        trace = []
+        sc = orc.forward(p, og, np.asarray(subs), np.asarray(rels), 3, act="relu", trace=trace).numpy()
+        labels = np.zeros((len(idx), n_ent)); fl = np.zeros((len(idx), n_ent))
+        for i, q in enumerate(idx):
+            labels[i, np.asarray(loader.test_a[q])] = 1
+            fl[i, np.asarray(loader.filters[(int(subs[i]), int(rels[i]))])] = 1
+        cpu_ranks = np.asarray(orc.cal_ranks(sc, labels, fl))
+        t_tot += time.perf_counter() - t0
+        edges += sum(len(t["edges"]) for t in trace)
+        n_viol += int((np.abs(g - sc) > 2e-5 + 1e-4 * np.abs(sc)).sum())
+        max_err = max(max_err, float(np.abs(g - sc).max()))
+        zero_ok &= bool(np.array_equal(g == 0, sc == 0))
+        n_rank += len(cpu_ranks)
+        n_same += int(np.sum(g_ranks == cpu_ranks))
+        done += len(idx)
+    cpu = dict(value=edges / t_tot, unit="edges/s", cores=torch.get_num_threads(), kind="port", queries_per_s=done / t_tot,
+               sample="family evaluation graph, first %d test queries in batches of %d, oracle forward + cal_ranks, %.1f s" % (done, bs, t_tot))
+    parity = dict(queries_checked=done, zero_pattern_equal=bool(zero_ok), rtol=1e-4, atol=2e-5, elements_beyond_rtol_atol=n_viol,
+                  max_abs_score_err=max_err, ranks_identical_to_cpu_path="%d of %d" % (n_same, n_rank),
+                  parity=bool(zero_ok and n_viol == 0 and n_same == n_rank))
+    return cpu, parity
+
+
+def bench_temporal(args, dist, world, rank, engine, scaling="weak"):
     """--config C5: BASELINE configs[4], the temporal interpolation path (T_RED_GNN, model_cuda.py layout) on the ICEWS14-shaped synthetic:
     a step = forward of B (head, relation, time) queries (expansion + 5 fused temporal layers + readout), queries sharded over ranks.
     The CPU leg is the oracle's temporal_forward on a few of the same queries (scores compared at the fp64-anchored tolerance)."""
@@ -325,7 +430,7 @@ def bench_temporal(args, dist, world, rank, engine):
     out = {
         "metric": "edges aggregated/sec + MRR-eval queries/sec, family KG n_layer=3 at 1/2/4/8 GPU",
         "value": edges / dt, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": "C5 ICEWS14-shaped temporal synthetic %d entities / %d relation rows / %d time ids / %d quadruples (seed 1234), "
                                "interpolation path n_layer=%d hidden_dim=%d attn_dim=%d, step = expansion + fused temporal layers + readout, "
@@ -333,6 +438,130 @@ def bench_temporal(args, dist, world, rank, engine):
                    "batch_per_gpu": B, "global_batch": B * world, "sharding": "queries strided over ranks" if world > 1 else "none"},
         "eval_queries_per_s": B * world * args.steps / dt, "edges_per_step": edges / args.steps,
         "roofline": roof, "cpu_baseline": cpu, "parity": parity, "rg_version": int(_lib_version()),
+    }
+    print(json.dumps(out))
+
+
+def bwd_rooflines(bwd_ms, edges_per_level, d, ap, stored=None):
+    """Roofline object of the backward's message-passing launches (rg_layer_bwd = layer_bwd_kernel + bwd_combine_kernel + drel_kernel)
+    from per-call records (ms, level, n_old).  Algorithmic bytes: layer_bwd_kernel E (4d + 16) + N_old (4d + 4ap) - one
+    grad_agg row gathered per edge, one gradient row and one attention-projection row written per source node - and drel_kernel
+    E (4d + 8 + 4ap).  Like the forward's rows, the gathered grad_agg rows of a query are L2-resident: the object that binds prices
+    the gathered rows (both kernels gather one row per edge: 2 E 4d) against the L2 gather rate; hbm_algorithmic is kept beside it."""
+    if not bwd_ms:
+        return None
+    t = sum(m for m, _, _ in bwd_ms) * 1e-3
+    e_tot = sum(edges_per_level[lvl - 1] for _, lvl, _ in bwd_ms)
+    b_main = sum(edges_per_level[lvl - 1] * (4.0 * d + 16) + n_old * (4.0 * d + 4 * ap) for _, lvl, n_old in bwd_ms)
+    b_drel = sum(edges_per_level[lvl - 1] * (4.0 * d + 8 + 4 * ap) for _, lvl, _ in bwd_ms)
+    rows = 2.0 * e_tot * 4 * d
+    n = len(bwd_ms)
+    out = dict(bound="l2-gather", kernel="rg_layer_bwd launches (layer_bwd_kernel + bwd_combine_kernel + drel_kernel)", achieved=rows / t / 1e9,
+               peak=L2_GATHER_PEAK / 1e9, unit="GB/s", frac=rows / t / L2_GATHER_PEAK, traffic=None, launches=n, avg_launch_ms=t * 1e3 / n,
+               bytes="gathered grad_agg rows of both kernels: 2 E * 4 * d", kernel_edges_per_s=e_tot / t,
+               hbm_algorithmic=dict(achieved=(b_main + b_drel) / t / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", frac=(b_main + b_drel) / t / HBM_PEAK,
+                                    layer_bwd_kernel_bytes_per_launch=b_main / n, drel_kernel_bytes_per_launch=b_drel / n))
+    if stored:          # per-kernel split of the same step from the committed rocprofv3 --kernel-trace --stats run
+        out["per_kernel"] = stored
+    return out
+
+
+def bench_train(args, dist, world, rank, engine):
+    """--train: a step = one training step of the reference's loop (base_model.py:45-83: forward in train mode with dropout, the
+    reference's loss, backward through the HIP adjoints, Adam) on --batch train triples of the synthetic KG, queries split over the ranks
+    (gradients summed by one flat all-reduce).  value = edges aggregated per second, forward + backward."""
+    from red_gnn_amd.base_model import reference_loss
+    from red_gnn_amd.load_data import DataLoader
+    from red_gnn_amd.models import RED_GNN_trans, pad_attn
+    from red_gnn_amd.sharding import allreduce_gradients
+    from red_gnn_amd.synthetic import SHAPES, make_shape
+    shape = SHAPES[args.config]
+    kg = make_shape(args.config, seed=1234)
+    loader = DataLoader(ids=dict(n_ent=kg.n_ent, n_rel=kg.n_rel, facts=kg.facts, train=kg.train, valid=kg.valid, test=kg.test), verbose=False)
+    p = Params(shape, kg.n_rel)
+    p.dropout = 0.1
+    torch.manual_seed(1234)
+    model = RED_GNN_trans(p, loader).cuda().train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)
+    B = args.batch
+    trip = loader.train_data[(np.arange(B * world) % len(loader.train_data))[rank::world]]
+    tails = torch.as_tensor(trip[:, 2], device="cuda")
+    d, n_layer = shape["hidden_dim"], shape["n_layer"]
+    fwd_ev, dense_ev, bwd_ev = [], [], []
+    if not args.no_kernel_events:
+        engine.KERNEL_EVENTS, engine.BWD_EVENTS = fwd_ev, bwd_ev
+    marks = []
+
+    def step(timed=False):
+        opt.zero_grad(set_to_none=True)
+        if timed:
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            e[0].record()
+        scores = model(trip[:, 0], trip[:, 1])
+        loss = reference_loss(scores, tails) * (B * world / len(trip))
+        if timed:
+            e[1].record()
+        loss.backward()
+        if timed:
+            e[2].record()
+            marks.append(e)
+        if dist is not None:
+            allreduce_gradients(list(model.parameters()), dist)
+        opt.step()
+        return model.last_stats
+
+    for _ in range(max(args.warmup, 2)):
+        step()
+    fwd_ev.clear(); bwd_ev.clear()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    edges = 0
+    for _ in range(args.steps):
+        st = step(timed=True)
+        edges += sum(st["n_edges"])
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt, float(edges)], device="cuda", dtype=torch.float64)
+    if dist is not None:
+        tmax = tt.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = tt.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt, edges = float(tmax[0]), float(tsum[1])
+    engine.KERNEL_EVENTS = engine.BWD_EVENTS = None
+    if rank != 0:
+        return
+    e_lvl = st["n_edges"]
+    fwd_ms = [(a.elapsed_time(b), ne, nn) for (a, b, ne, nn) in fwd_ev]
+    bwd_ms = [(a.elapsed_time(b), lvl, n_old) for (a, b, lvl, n_old) in bwd_ev]
+    roof_f, per_hop = layer_rooflines(fwd_ms, d, n_layer)
+    stored = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "train_kernels.json")) as f:
+            doc = json.load(f)
+        if doc.get("config") == args.config and int(doc.get("batch", -1)) == B and int(doc.get("rg_version", -1)) == int(_lib_version()):
+            stored = doc.get("kernels")
+    except (OSError, ValueError):
+        pass
+    roof_b = bwd_rooflines(bwd_ms, e_lvl, d, pad_attn(shape["attn_dim"]), stored)
+    ms_f = sum(m[0].elapsed_time(m[1]) for m in marks) / len(marks)
+    ms_b = sum(m[1].elapsed_time(m[2]) for m in marks) / len(marks)
+    out = {
+        "metric": "edges aggregated/sec + MRR-eval queries/sec, family KG n_layer=3 at 1/2/4/8 GPU",
+        "value": 2.0 * edges / dt, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s synthetic KG %d entities / %d relations / %d triples (seed 1234), n_layer=%d hidden_dim=%d attn_dim=%d, "
+                               "TRAINING step = forward (dropout 0.1) + reference loss + HIP backward + Adam, %d train triples per GPU; value counts "
+                               "every edge once in the forward and once in the backward"
+                               % (args.config, kg.n_ent, kg.n_rel, shape["n_triples"], n_layer, d, shape["attn_dim"], B),
+                   "batch_per_gpu": B, "global_batch": B * world,
+                   "sharding": "train triples strided over ranks, gradients summed by one flat all-reduce" if world > 1 else "none"},
+        "forward_ms": ms_f, "backward_ms": ms_b, "optimizer_and_host_ms": dt / args.steps * 1e3 - ms_f - ms_b,
+        "edges_per_step": edges / args.steps, "roofline": roof_b, "roofline_forward": roof_f, "per_hop_forward": per_hop,
+        "cpu_baseline": None, "rg_version": int(_lib_version()),
     }
     print(json.dumps(out))
 
@@ -349,10 +578,17 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=1024, help="queries per GPU per step")
     ap.add_argument("--config", default="C2")
-    ap.add_argument("--dense-precision", default=None, choices=["f32", "f16x2"],
-                    help="matrix products of the fused dense kernel (default: the model's default)")
-    ap.add_argument("--no-dense-f32", action="store_true", help="skip the secondary measurement of the step with exact-fp32 dense products "
-                    "(profiling runs: keeps the launch sequence to the timed steps)")
+    ap.add_argument("--dense-precision", default=None, choices=["f32", "f16x3", "f16x2"],
+                    help="matrix products of the fused dense kernel (default: the model's default, f16x3 = fp32 arithmetic as exact three-term "
+                         "f16 splits; f16x2 = 22-bit operands, opt-in)")
+    ap.add_argument("--no-dense-f32", action="store_true", help="skip the secondary measurement of the step with the dense products on the f32 "
+                    "MFMA forms (profiling runs: keeps the launch sequence to the timed steps)")
+    ap.add_argument("--global-batch", type=int, default=0, help="strong scaling: this many queries per step over ALL ranks (BASELINE's C4 = 256 "
+                    "over 4, C5 = 256 over 8); default 0 = weak scaling with --batch queries per GPU")
+    ap.add_argument("--eval-collective", default="allgather", choices=["allgather", "allreduce"],
+                    help="N > 1: all-gather of the score shards (north_star) + 4-sum all-reduce, or the 4-sum all-reduce only")
+    ap.add_argument("--train", action="store_true", help="a step = one training step (forward + reference loss + HIP backward + Adam) on --batch "
+                    "train triples (default 256); roofline objects for the backward kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-family-eval", action="store_true", help="skip BaseModel.evaluate on the real family graph (runs after the timed region "
@@ -393,8 +629,20 @@ def main():
     from red_gnn_amd.synthetic import SHAPES, make_shape
     from red_gnn_amd.utils import cal_ranks_csr
 
+    if args.global_batch:            # strong scaling: the per-GPU share of a fixed global batch
+        if args.global_batch % world:
+            raise SystemExit("--global-batch %d is not a multiple of the %d ranks" % (args.global_batch, world))
+        args.batch = args.global_batch // world
+    scaling = "strong" if args.global_batch else "weak"
+    if args.train:
+        if "--batch" not in sys.argv and not args.global_batch:
+            args.batch = 256
+        bench_train(args, dist, world, rank, engine)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     if args.config == "C5":          # the temporal interpolation path has its own model and step
-        bench_temporal(args, dist, world, rank, engine)
+        bench_temporal(args, dist, world, rank, engine, scaling)
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -439,8 +687,9 @@ def main():
             if dist is not None:
                 while pending:
                     pending.pop()[0].wait()
-                # north star: RCCL all-gather of the score shards over xGMI; asynchronous, joined one step later
-                pending.append(gather_scores(scores, dist, async_op=True) + (scores,))
+                if args.eval_collective == "allgather":
+                    # north star: RCCL all-gather of the score shards over xGMI; asynchronous, joined one step later
+                    pending.append(gather_scores(scores, dist, async_op=True) + (scores,))
                 sums = reduce_metrics(sums, dist)
             last["scores"], last["ranks"] = scores, ranks
         return sums, model.last_stats
@@ -480,7 +729,8 @@ def main():
     gpu_scores = last["scores"].cpu().numpy() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
     gpu_ranks = last["ranks"].double().cpu().numpy() if gpu_scores is not None else None
 
-    # the same step with the dense kernel's products on exact-fp32 MFMA (after the timed region; the default is the f16-split form)
+    # the same step with the dense kernel's products on the f32 MFMA forms (after the timed region; the default runs them as exact
+    # three-term f16 splits)
     dense_f32 = None
     if model.dense_precision != "f32" and not args.graphs and not args.no_dense_f32:
         saved_prec, saved_ev = model.dense_precision, (engine.KERNEL_EVENTS, engine.DENSE_EVENTS)
@@ -510,11 +760,11 @@ def main():
         engine.KERNEL_EVENTS, engine.DENSE_EVENTS = saved_ev
 
     # second half of the metric's name, after (never inside) the timed region
-    family = None if args.no_family_eval else family_eval(dist, world, engine)
+    family = None if args.no_family_eval else family_eval(dist, world, engine, cpu_leg=not args.no_cpu_baseline, rank=rank)
 
     if rank == 0:
         version = int(_lib.lib().rg_version())
-        roof, roof_l2, per_hop = layer_rooflines(ev_ms, d, shape["n_layer"], stored_traffic(args.config, B, version))
+        roof, per_hop = layer_rooflines(ev_ms, d, shape["n_layer"], stored_traffic(args.config, B, version))
         traffic_entry = stored_traffic(args.config, B, version)
         roof_dense = dense_roofline(dense_ms, d, shape["attn_dim"], shape["n_layer"], B, model.dense_precision) if dense_ms else None
         if roof_dense and traffic_entry:
@@ -533,22 +783,23 @@ def main():
         out = {
             "metric": "edges aggregated/sec + MRR-eval queries/sec, family KG n_layer=3 at 1/2/4/8 GPU",
             "value": total_edges / dt, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "dense_precision": ("f16x2: fp32 operands as two-term f16 splits (22 bits), fp32 accumulation; dense_f32 = the same step with "
-                                "exact-fp32 MFMA products" if model.dense_precision == "f16x2" else "f32"),
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+            "dtype": DTYPE_OF[dense_kernel_of(d, model.dense_precision)[1]], "data": "synthetic",
+            "dense_precision": DENSE_NOTE[dense_kernel_of(d, model.dense_precision)[1]],
             "dense_f32": dense_f32,
             "config": {"workload": "%s synthetic KG %d entities / %d relations / %d triples (seed 1234), n_layer=%d hidden_dim=%d attn_dim=%d, "
                                    "eval step = expansion + fused layers + GRU/readout + filtered ranking, %d queries per GPU"
                                    % (args.config, kg.n_ent, kg.n_rel, shape["n_triples"], shape["n_layer"], d, shape["attn_dim"], B),
                        "batch_per_gpu": B, "global_batch": B * world,
-                       "sharding": ("queries dealt over ranks by estimated cost (equal counts), scores all-gathered (%s)"
-                                    % ("RCCL" if args.backend == "nccl" else args.backend + ", not RCCL")) if world > 1 else "none"},
+                       "sharding": ("queries dealt over ranks by estimated cost (equal counts), %s (%s)"
+                                    % ("scores all-gathered + 4 metric sums all-reduced" if args.eval_collective == "allgather"
+                                       else "4 metric sums all-reduced only", "RCCL" if args.backend == "nccl" else args.backend + ", not RCCL"))
+                       if world > 1 else "none"},
             "eval_queries_per_s": B * world * args.steps / dt,
             "edges_per_step": total_edges / args.steps,
             "mrr_of_random_init": float(s[0] / s[3]),
             "family_eval_queries_per_s": family["queries_per_s"] if family else None,
-            "roofline": roof, "roofline_l2": roof_l2, "per_hop": per_hop, "roofline_dense": roof_dense, "cpu_baseline": cpu,
+            "roofline": roof, "per_hop": per_hop, "roofline_dense": roof_dense, "cpu_baseline": cpu,
             "parity": parity, "family_eval": family, "rg_version": version,
         }
         print(json.dumps(out))

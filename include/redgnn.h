@@ -244,7 +244,24 @@ int64_t rg_dense_scratch_bytes(int32_t d, int32_t precision);
  *   0  v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulation (what the reference's fp32 GEMMs compute up to sum order)
  *   1  every fp32 operand as a two-term f16 split (22 significant bits, per-row power-of-two scaling), three
  *      v_mfma_f32_16x16x32_f16 per product with fp32 accumulation: errors of a few 1e-7 of a dot product's largest terms instead
- *      of 1e-7, at 3/16 of the matrix-pipe time */
+ *      of 1e-7, at 3/16 of the matrix-pipe time
+ *   2  every fp32 operand as an EXACT three-term f16 split (hi + mid + lo = all 24 bits; csrc/split3.h), the six partial products of
+ *      order >= 2^-22 per product on v_mfma_f32_16x16x32_f16 / _bf8_bf8 with fp32 accumulation: fp32 arithmetic (operands exact,
+ *      products good to 2^-31, fp32 sums) at 6/16 of the matrix-pipe time of precision 0.  d <= 64; at d = 128 it runs precision 0's
+ *      kernel.  The model's default. */
+
+/* Test hook of precision 2's operand form: splits each of the n_rows rows of `cols` floats on the device exactly as the dense kernels
+ * do (row scale = the power of two that takes the row's largest magnitude to [2^14, 2^15)) and writes back[n_rows, cols] =
+ * (hi + mid + lo) / scale - bitwise equal to x for every element within 2^-15 of its row's largest magnitude (smaller ones: within 2^-39 of that largest) - and, if parts is not
+ * NULL, parts[n_rows, cols, 4] = {hi, mid, lo, the bf8 (weights') form of lo}, scaled. */
+int rg_split3_roundtrip(const float* x, int64_t n_rows, int32_t cols, float* back, float* parts, void* stream);
+/* Test hook of precision 2's products: runs the d <= 64 kernel of rg_dense_fwd(precision = 2) on rows of d floats (ld = d) and writes
+ * out[n, d] = one of its matrix products instead of the new state: which = 1: act(W_h agg); 2: weight_ih[2d:3d] x with
+ * x = act(W_h agg); 3: weight_hh[2d:3d] h0 (h0 = hidden_prev gathered by prev_idx).  With one-hot operand rows (times powers of two)
+ * a product is a column of the weight matrix and must come out bit for bit: the six partial products of csrc/split3.h are all there. */
+int rg_split3_product_check(int32_t which, int64_t n, int32_t d, const float* agg, const float* hidden_prev, const int32_t* prev_idx,
+                            const float* W_h, int32_t act, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                            float* out, void* stream);
 
 /* ---- filtered ranking: replaces utils.py:7-14 cal_ranks (+ the filter loop base_model.py:107-115)
  * scores device fp32 [B, n_ent]; answers / filters as CSR over queries (device int32):

@@ -342,7 +342,8 @@ static int dense_fwd_impl(int64_t n, const int32_t* n_dev, int64_t n_hint, int32
                           float* a_s_out, const float* W_final, const int32_t* nodes, int32_t n_ent, float* scores_all,
                           float* hidden_out, int32_t precision, void* scratch, int64_t scratch_bytes, void* stream) {
   RG_CHECK(agg && W_h && w_ih && w_hh && b_ih && b_hh && hidden_out, "rg_dense_fwd: NULL argument");
-  RG_CHECK(precision == 0 || precision == 1, "rg_dense_fwd: precision=%d (0 = f32 MFMA, 1 = two-term f16 split)", precision);
+  RG_CHECK(precision >= 0 && precision <= 2, "rg_dense_fwd: precision=%d (0 = f32 MFMA, 1 = two-term f16 split, 2 = exact three-term f16 split)",
+           precision);
   RG_CHECK(!prev_idx || hidden_prev, "rg_dense_fwd: prev_idx given without hidden_prev");
   RG_CHECK((d >= 1 && d <= 64) || d == 128, "rg_dense_fwd: hidden_dim %d not supported by the fused kernel (<= 64, or 128)", d);
   RG_CHECK(ld >= d && ld % 4 == 0 && ld <= 128, "rg_dense_fwd: ld=%d", ld);
@@ -362,8 +363,11 @@ static int dense_fwd_impl(int64_t n, const int32_t* n_dev, int64_t n_hint, int32
   A.hidden_out = (float4*)hidden_out; A.act = act;
   A.n_tiles = (int)rg::ceil_div(n, 16);
   hipStream_t s = (hipStream_t)stream;
+  // (d = 128: the exact three-term kernel is not built for streamed weights; precision 2 takes the f32 MFMA kernel there - the same
+  // fp32 arithmetic, slower)
   if (d == 128) return precision == 1 ? rg::dense128_split_launch(A, scratch, scratch_bytes, s) : rg::dense128_launch(A, s);
   if (precision == 1) return rg::dense_split_launch(A, s);
+  if (precision == 2) return rg::dense_split3_launch(A, s);
   return d <= 32 ? launch<2, false>(A, s) : launch<4, false>(A, s);
 }
 

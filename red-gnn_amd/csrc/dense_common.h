@@ -33,6 +33,7 @@ struct DenseArgs {
   // training variant (rg_dense_train_fwd): dropout mask in, GRU input and gate workspace out
   const float* mask = nullptr;   // [n][ld] 0 or 1/(1-p), or null
   float* x_out = nullptr;        // [n][ld]  act(W_h agg) * mask
+  int probe = 0;                 // three-term kernel, test hook (rg_split3_product_check): 1 = hidden_out <- act(W_h agg), 2 = W_in x, 3 = W_hn h
   float* ws_out = nullptr;       // [n][5][d] = {r, z, n, h0, W_hn h0 + b_hn}: the workspace layout of aten's fused GRU cell
 };
 
@@ -48,6 +49,8 @@ static __device__ __forceinline__ float fast_tanh(float x) {
 int dense128_launch(const DenseArgs& A, hipStream_t s);
 // d <= 64 with the products as two-term f16 splits (dense_split.hip)
 int dense_split_launch(const DenseArgs& A, hipStream_t s);
+// d <= 64 with the products as exact three-term f16 splits = fp32 arithmetic on the f16 pipe (dense_split3.hip)
+int dense_split3_launch(const DenseArgs& A, hipStream_t s);
 // d = 128 with split products: the weights' split image goes through a caller-provided scratch (dense128_split.hip)
 int64_t dense128_split_scratch_bytes();
 int dense128_split_launch(const DenseArgs& A, void* scratch, int64_t scratch_bytes, hipStream_t s);

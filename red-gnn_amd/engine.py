@@ -19,6 +19,8 @@ FORCE_WALK = 0
 # (start_event, end_event, n_rows) per rg_dense_fwd launch
 KERNEL_EVENTS = None
 DENSE_EVENTS = None
+# ... and (start_event, end_event, n_edges, n_old) per rg_layer_bwd call (its kernels: layer_bwd_kernel, bwd_combine_kernel, drel_kernel)
+BWD_EVENTS = None
 
 
 def _require_gpu(device):
@@ -402,12 +404,19 @@ def layer_bwd(frontier, graph, level, nodes_old, hidden, rela, d, a_s, a_r, a_q,
     g_b = torch.zeros(1, dtype=torch.float32, device=dev)
     nbytes = _lib.lib().rg_layer_bwd_scratch_bytes(frontier.handle, graph.handle, ld, ap)
     scratch = frontier.scratch(nbytes)
+    ev = None
+    if BWD_EVENTS is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
     _lib.check(_lib.lib().rg_layer_bwd(frontier.handle, graph.handle, level, n_old,
                                        _lib.ptr(hidden), _lib.ptr(rela), d, ld, _lib.ptr(a_s), _lib.ptr(a_r),
                                        _lib.ptr(a_q), ap, _lib.ptr(w_alpha), _lib.ptr(b_alpha), attn_dim,
                                        _lib.ptr(grad_agg), _lib.ptr(g_h), _lib.ptr(g_rela), _lib.ptr(g_as),
                                        _lib.ptr(g_ar), _lib.ptr(g_aq), _lib.ptr(g_w), _lib.ptr(g_b), _lib.ptr(scratch), nbytes,
                                        _lib.stream_ptr()))
+    if ev is not None:
+        ev[1].record()
+        BWD_EVENTS.append((ev[0], ev[1], level, n_old))
     return g_h, g_rela, g_as, g_ar, g_aq, g_w, g_b
 
 
@@ -456,7 +465,7 @@ def dense_supported(d, attn_dim):
     return bool(_lib.lib().rg_dense_fwd_supported(d, attn_dim))
 
 
-DENSE_PRECISIONS = {"f32": 0, "f16x2": 1}
+DENSE_PRECISIONS = {"f32": 0, "f16x2": 1, "f16x3": 2}
 
 
 def dense_scratch(d, precision, device):
@@ -468,7 +477,8 @@ def dense_scratch(d, precision, device):
 def dense_fwd(agg, hidden_prev, prev_idx, d, W_h, act, gate, Ws_next=None, attn_dim=0, ap=0, W_final=None, nodes=None,
               n_ent=0, scores_all=None, precision="f32"):
     """Fused W_h + act + GRU step (+ next layer's a_s, + readout) on the matrix cores (rg_dense_fwd).  precision: "f32" = exact
-    fp32 MFMA, "f16x2" = two-term f16 splits of every operand (22 bits, fp32 accumulation; see include/redgnn.h).
+    fp32 MFMA, "f16x3" = exact three-term f16 splits of every operand (fp32 arithmetic on the f16 pipe), "f16x2" = two-term f16
+    splits (22 bits, fp32 accumulation); see include/redgnn.h.
     Returns (hidden_new [n, ld], a_s_next [n, ap] or None)."""
     n, ld = agg.shape
     hidden = torch.empty_like(agg)

@@ -11,7 +11,7 @@ What is different inside (nothing is different outside):
     its adjoint rg_layer_bwd; the three attention Linear layers are hoisted to per-node /
     per-relation / per-query projections (exact re-association, SURVEY.md §9);
   * dense algebra that is not on the E-proportional path (W_h, GRU cell, hoisted projections, W_final): inference runs it
-    in one matrix-core kernel per layer (rg_dense_fwd: f16-split products by default, see dense_precision), and from the third call of a (graph, batch size) on replays the whole
+    in one matrix-core kernel per layer (rg_dense_fwd: fp32 arithmetic as exact three-term f16 splits by default, see dense_precision), and from the third call of a (graph, batch size) on replays the whole
     forward as one captured HIP graph (_GraphedInference); training runs W_h + act + carry + dropout + GRU step as one kernel
     too (_DenseStep: rg_dense_train_fwd / rg_dense_train_bwd), with the weight gradients - sums over millions of node rows -
     issued as row-chunked batched GEMMs (``tall_linear`` / ``_gram_tn``: a plain [m,n] = G^T X product lands on a handful of
@@ -322,9 +322,11 @@ class RED_GNN_trans(nn.Module):
         self._frontiers = engine.FrontierPool()
         self._last_stats = None
         self.fused_dense = True      # inference: W_h + GRU + projections + readout in one MFMA kernel (rg_dense_fwd)
-        # matrix products of that kernel: "f16x2" = two-term f16 splits with fp32 accumulation (22-bit operands; measured against fp64 its
-        # results are as close as the exact kernel's, whose error is set by the fast sigmoid/tanh), "f32" = exact fp32 MFMA
-        self.dense_precision = "f16x2"
+        # matrix products of that kernel.  "f16x3" (default) = fp32 arithmetic on the f16 matrix pipe: every fp32 operand carried
+        # exactly as a three-term f16 split, six partial products per product, fp32 accumulation (csrc/split3.h; d <= 64, at d = 128
+        # it runs the f32 MFMA kernel); "f32" = v_mfma_f32_16x16x4_f32; "f16x2" = two-term splits (22-bit operands: narrower than the
+        # reference's fp32 nn.Linear / nn.GRU, opt-in only)
+        self.dense_precision = "f16x3"
         self.use_graphs = True       # inference: replay a captured HIP graph per (graph, batch size) from the third call on
         self._graphed, self._seen, self._hints, self._pending_key, self._graph_failed = {}, {}, {}, None, set()
 

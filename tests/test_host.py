@@ -234,29 +234,38 @@ def test_bench_byte_model():
 
 
 def test_bench_roofline_objects():
-    """bench.layer_rooflines on round 1's measured launches (C2, B=1024: profiles/r01/final_pmc_B1024.json durations): the
-    contract's HBM object may exceed 1 (its byte model counts L2-served rows as HBM), the L2-gather object - the roof that
-    binds - must not; stored PMC traffic is only attached to the workload and kernel version it was measured on."""
+    """bench.layer_rooflines on round 1's measured launches (C2, B=1024: profiles/r01/final_pmc_B1024.json durations): `roofline` is
+    the roof that binds - gathered rows against the L2 gather rate, frac <= 1 - with SURVEY 8d's algorithmic-HBM figure (which may
+    exceed 1: its byte model counts L2-served rows as HBM) beside it; stored PMC traffic and L2 request bytes are only attached to
+    the workload and kernel version they were measured on."""
     import json
     import bench
     ev = [(0.43, 1.33e6, 1.29e6), (4.03, 52.0e6, 8.2e6), (7.15, 388.5e6, 10.0e6)] * 4
-    roof, l2, hops = bench.layer_rooflines(ev, 64, 3)
-    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["launches"] == 12 and roof["traffic"] is None
-    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12 and roof["frac"] > 1.0
-    assert l2["bound"] == "l2-gather" and 0.0 < l2["frac"] <= 1.0
+    roof, hops = bench.layer_rooflines(ev, 64, 3)
+    assert roof["bound"] == "l2-gather" and roof["unit"] == "GB/s" and roof["launches"] == 12 and roof["traffic"] is None
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12 and 0.0 < roof["frac"] <= 1.0
+    alg = roof["hbm_algorithmic"]
+    assert alg["frac"] > 1.0 and abs(alg["frac"] - alg["achieved"] / alg["peak"]) < 1e-12
+    assert abs(alg["bytes_per_launch"] - sum(bench.algorithmic_bytes(e, n, 64) for _, e, n in ev) / 12) < 1.0
+    assert "l2_request_bytes" not in roof
     assert [h["hop"] for h in hops] == [0, 1, 2] and all(0.0 < h["l2_gather_frac"] <= 1.0 for h in hops)
     assert hops[1]["l2_gather_frac"] < 0.5 * hops[2]["l2_gather_frac"]            # the expanding hop is the one far below its roof
-    assert bench.layer_rooflines([], 64, 3) == (None, None, None)
+    assert bench.layer_rooflines([], 64, 3) == (None, None)
+    # this round's launches (C2, B=1024): the binding fraction stays below 1 at the fastest launch times measured
+    ev3 = [(0.30, 269705, 214497), (1.70, 51608885, 9067818), (6.58, 389993435, 10239990)] * 2
+    assert 0.5 < bench.layer_rooflines(ev3, 64, 3)[0]["frac"] <= 1.0
     with tempfile.TemporaryDirectory() as td:
         path = os.path.join(td, "t.json")
         with open(path, "w") as f:
-            json.dump({"entries": [{"config": "C2", "batch": 1024, "rg_version": 7, "hbm_bytes_per_launch": 4.5e9, "source": "x"}]}, f)
+            json.dump({"entries": [{"config": "C2", "batch": 1024, "rg_version": 7, "hbm_bytes_per_launch": 4.5e9, "source": "x",
+                                    "per_kernel": {"a": {"TCC_HIT_sum": [1.0e9, 2.0e8], "TCC_MISS_sum": [1.0e8]}}}]}, f)
         assert bench.stored_traffic("C2", 1024, 7, path)["hbm_bytes_per_launch"] == 4.5e9
         assert bench.stored_traffic("C4", 1024, 7, path) is None and bench.stored_traffic("C2", 256, 7, path) is None
         assert bench.stored_traffic("C2", 1024, 8, path) is None and bench.stored_traffic("C2", 1024, 7, path + ".missing") is None
         e = bench.stored_traffic("C2", 1024, 7, path)
-    roof, _, _ = bench.layer_rooflines(ev, 64, 3, e)
+    roof, _ = bench.layer_rooflines(ev, 64, 3, e)
     assert roof["traffic"] == 4.5e9 and 0.0 < roof["hbm_measured_frac"] < 1.0
+    assert roof["l2_request_bytes"] == 1.3e9 * 128 / 3
     # the committed file only ever answers for the library version it was measured with
     from red_gnn_amd import _lib
     with open(bench.TRAFFIC_FILE) as f:
@@ -265,9 +274,24 @@ def test_bench_roofline_objects():
     assert _lib.lib().rg_version() >= 2
 
 
+def test_bench_backward_roofline_object():
+    """bench.bwd_rooflines (the --train line): gathered rows of both backward kernels against the L2 gather rate, frac <= 1 at the
+    launch times measured in round 2 (C2, B=256: 18.8 ms of backward, ~8 ms of it in rg_layer_bwd)."""
+    import bench
+    e_lvl = [67000, 12.9e6, 97.5e6]
+    rec = [(4.9, 3, 2.27e6), (2.6, 2, 53600), (0.4, 1, 256)]
+    r = bench.bwd_rooflines(rec, e_lvl, 64, 8)
+    assert r["bound"] == "l2-gather" and 0.0 < r["frac"] <= 1.0 and r["launches"] == 3
+    main = sum(e_lvl[l - 1] * (4 * 64 + 16) + n * (4 * 64 + 32) for _, l, n in rec)
+    assert abs(r["hbm_algorithmic"]["layer_bwd_kernel_bytes_per_launch"] - main / 3) < 1.0
+    assert abs(r["hbm_algorithmic"]["drel_kernel_bytes_per_launch"] - sum(e_lvl) * (4 * 64 + 8 + 32) / 3) < 1.0
+    assert bench.bwd_rooflines([], e_lvl, 64, 8) is None
+
+
 def test_bench_dense_roofline_per_precision():
-    """bench.dense_roofline prices the exact-fp32 dense kernel against the f32 matrix pipe and the f16-split kernel against HBM by its
-    rows (with the issued f16 MFMA rate beside it): launches of C2 / B=1024 as measured in round 2."""
+    """bench.dense_roofline prices the f32-MFMA dense kernel against the f32 matrix pipe, the exact three-term kernel (the default)
+    against the f16 matrix pipe by the six MFMAs it issues per product, and the opt-in two-term kernel against HBM by its rows (with
+    the issued f16 MFMA rate beside it): launches of C2 / B=1024 as measured in rounds 2 and 3."""
     import bench
     rows = [1.3e6, 8.2e6, 10.0e6]
     f32 = bench.dense_roofline([(0.5, rows[0]), (3.2, rows[1]), (3.9, rows[2])] * 2, 64, 5, 3, 1024, "f32")
@@ -278,6 +302,12 @@ def test_bench_dense_roofline_per_precision():
     assert abs(sp["algorithmic_bytes_per_launch"] - per_launch) < 1e-6 * per_launch
     assert abs(sp["mfma"]["issued_f16_tflops"] - 3 * sp["useful_tflops"]) < 1e-9 and sp["mfma"]["frac"] < 1.0
     assert sp["mfma"]["useful_over_f32_mfma_peak"] > 1.0          # more useful flops per second than the f32 pipe could issue
+    s3 = bench.dense_roofline([(0.3, rows[0]), (2.4, rows[1]), (2.9, rows[2])] * 2, 64, 5, 3, 1024, "f16x3")
+    assert s3["bound"] == "mfma" and s3["kernel"] == "dense_split3_kernel" and s3["peak"] == 2500.0 and 0.0 < s3["frac"] < 1.0
+    assert abs(s3["achieved"] - 6 * s3["useful_tflops"]) < 1e-9 and 0.0 < s3["hbm_algorithmic_frac"] < 1.0
+    # at d = 128 the default precision runs the f32 MFMA kernel
+    assert bench.dense_kernel_of(128, "f16x3") == ("dense128_kernel", "f32") and bench.dense_kernel_of(48, "f16x3")[0] == "dense_split3_kernel"
+    assert bench.DTYPE_OF["f16x3"] == "f32" and bench.DTYPE_OF["f16x2"] != "f32"
 
 
 def test_loader_id_cache_roundtrip():
