@@ -442,6 +442,129 @@ def bench_temporal(args, dist, world, rank, engine, scaling="weak"):
     print(json.dumps(out))
 
 
+def bench_extrapolation(args, dist, world, rank, engine, scaling="weak"):
+    """--config X: SURVEY 8 f4, the temporal EXTRAPOLATION path (Temporal/extrapolation/model_cuda_new_embedding.py) on the ICEWS14-shaped
+    synthetic: a step = forward of B (subject, relation, time) queries late in the year (full 120-day windows): windowed expansion +
+    3 fused layers + classifier + per-query softmax.  With --train the step also runs the loss of main.py:303-308 and the backward
+    (rg_xlayer_bwd).  CPU leg: the oracle's extrap_forward on two of the queries (parity UNPINNED for this model file)."""
+    from red_gnn_amd import extrapolation as X
+    from red_gnn_amd.synthetic import SHAPES, make_extrapolation_shape
+    import torch.nn.functional as F
+    sh = SHAPES["X"]
+    data, n_ent, n_rel, gran = make_extrapolation_shape("X", seed=1234)
+    d, n_layer = sh["hidden_dim"], sh["n_layer"]
+
+    class P:
+        pass
+
+    p = P()
+    p.n_ent, p.n_rel, p.data, p.time_granularity, p.hidden_dim, p.attn_dim, p.n_layer, p.act, p.device = n_ent, n_rel, data, gran, d, sh["attn_dim"], n_layer, "relu", "cuda"
+    torch.manual_seed(1234)
+    model = X.T_RED_GNN(p).cuda()
+    model.train(args.train)
+    B = args.batch
+    late = np.flatnonzero(data[:, 3] // gran >= 200)
+    q = data[np.sort(np.random.default_rng(1234).choice(late, B * world, replace=False))[rank::world]]
+
+    class Q:
+        src_idx, rel_idx, ts = q[:, 0], q[:, 1], q[:, 3]
+
+    target = torch.as_tensor(q[:, 2], dtype=torch.long).cuda()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3) if args.train else None
+    kernel_events = []
+    if not args.no_kernel_events:
+        engine.KERNEL_EVENTS = kernel_events
+
+    def step():
+        if args.train:
+            opt.zero_grad(set_to_none=True)
+            score, _ = model(Q)
+            F.nll_loss(torch.log(F.softmax(score, dim=1) + 1e-12), target).backward()
+            if dist is not None:
+                from red_gnn_amd.sharding import allreduce_gradients
+                allreduce_gradients([x for x in model.parameters()], dist)
+            opt.step()
+        else:
+            with torch.no_grad():
+                score, _ = model(Q)
+        return score, model.last_stats
+
+    for _ in range(max(args.warmup, 1)):
+        step()
+    kernel_events.clear()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    edges = 0
+    for _ in range(args.steps):
+        scores, st = step()
+        edges += sum(st["n_edges"])
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt, float(edges)], device="cuda", dtype=torch.float64)
+    if dist is not None:
+        tmax = tt.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = tt.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt, edges = float(tmax[0]), float(tsum[1])
+    engine.KERNEL_EVENTS = None
+    if rank != 0:
+        return
+    roof = None
+    ev_ms = [(e0.elapsed_time(e1), ne, nn) for (e0, e1, ne, nn) in kernel_events]
+    if ev_ms:
+        ms = sum(m for m, _, _ in ev_ms)
+        nbytes = sum(ne * (4 * d + 20) + nn * 4 * d for _, ne, nn in ev_ms)
+        rows = sum(ne for _, ne, _ in ev_ms) * 4.0 * d
+        roof = dict(bound="l2-gather", kernel="layer_fwd_kernel<TEMPORAL> with row windows (rg_xlayer_fwd)", achieved=rows / (ms * 1e-3) / 1e9,
+                    peak=L2_GATHER_PEAK / 1e9, unit="GB/s", frac=rows / (ms * 1e-3) / L2_GATHER_PEAK, traffic=None, launches=len(ev_ms),
+                    avg_launch_ms=ms / len(ev_ms), kernel_edges_per_s=sum(ne for _, ne, _ in ev_ms) / (ms * 1e-3),
+                    bytes="gathered state rows only: E * 4 * d (the kernel also gathers a relation and a time row per edge, both L2-resident tables)",
+                    hbm_algorithmic=dict(achieved=nbytes / (ms * 1e-3) / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", frac=nbytes / (ms * 1e-3) / HBM_PEAK,
+                                         bytes_per_launch=nbytes / len(ev_ms), note="SURVEY 8d, temporal: E (4d + 20) + N 4d"))
+    cpu = parity = None
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import redgnn_oracle as orc
+        n_s = 2
+        sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        off = orc.get_time_offset_list(data, gran)
+        t1 = time.perf_counter()
+        tr = []
+        ref, _, _ = orc.extrap_forward(sd, data, off, gran, n_ent, n_rel, q[:n_s, 0], q[:n_s, 1], q[:n_s, 3], n_layer, "relu", trace=tr)
+        t_cpu = time.perf_counter() - t1
+        ref64 = orc.extrap_forward(sd, data, off, gran, n_ent, n_rel, q[:n_s, 0], q[:n_s, 1], q[:n_s, 3], n_layer, "relu", dtype=torch.float64)[0].numpy()
+        model.eval()
+        with torch.no_grad():
+            class Q2:
+                src_idx, rel_idx, ts = q[:n_s, 0], q[:n_s, 1], q[:n_s, 3]
+            got = model(Q2)[0].cpu().numpy()
+        ref = ref.detach().numpy()
+        err_gpu, err_cpu = float(np.abs(got - ref64).max()), float(np.abs(ref - ref64).max())
+        tol_ok = bool(np.all(np.abs(got - ref) <= 2e-5 + 1e-4 * np.abs(ref)) or err_gpu <= 4 * max(err_cpu, 1e-7))
+        parity = dict(parity_at_bench_size=bool(tol_ok and np.array_equal(got == 0, ref == 0)), queries_checked=n_s,
+                      gpu_max_err_vs_fp64=err_gpu, cpu_fp32_max_err_vs_fp64=err_cpu,
+                      note="model_cuda_new_embedding.py: checked against the oracle only (parity unpinned, DESIGN 7)")
+        cpu = dict(value=sum(t["n_edges"] for t in tr) / t_cpu, unit="edges/s", cores=torch.get_num_threads(), kind="port",
+                   sample="%d of the batch's queries, oracle extrap_forward, %.1f s" % (n_s, t_cpu))
+    out = {
+        "metric": "edges aggregated/sec + MRR-eval queries/sec, family KG n_layer=3 at 1/2/4/8 GPU",
+        "value": (2.0 if args.train else 1.0) * edges / dt, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "X ICEWS14-shaped temporal EXTRAPOLATION synthetic %d entities / %d relations (+ self-loop) / %d days x %d / %d "
+                               "time-sorted rows (seed 1234), n_layer=%d hidden_dim=%d attn_dim=%d, 120-day windows, step = %s, %d queries per GPU"
+                               % (n_ent, n_rel, sh["n_time"], gran, len(data), n_layer, d, sh["attn_dim"],
+                                  "forward + loss + backward (rg_xlayer_bwd) + Adam; value counts every edge twice" if args.train
+                                  else "windowed expansion + fused layers + classifier + per-query softmax", B),
+                   "batch_per_gpu": B, "global_batch": B * world, "sharding": "queries strided over ranks" if world > 1 else "none"},
+        "eval_queries_per_s": B * world * args.steps / dt, "edges_per_step": edges / args.steps,
+        "roofline": roof, "cpu_baseline": cpu, "parity": parity, "rg_version": int(_lib_version()),
+    }
+    print(json.dumps(out))
+
+
 def bwd_rooflines(bwd_ms, edges_per_level, d, ap, stored=None):
     """Roofline object of the backward's message-passing launches (rg_layer_bwd = layer_bwd_kernel + bwd_combine_kernel + drel_kernel)
     from per-call records (ms, level, n_old).  Algorithmic bytes: layer_bwd_kernel E (4d + 16) + N_old (4d + 4ap) - one
@@ -634,6 +757,13 @@ def main():
             raise SystemExit("--global-batch %d is not a multiple of the %d ranks" % (args.global_batch, world))
         args.batch = args.global_batch // world
     scaling = "strong" if args.global_batch else "weak"
+    if args.config == "X":           # temporal extrapolation (forward, or a training step with --train)
+        if "--batch" not in sys.argv and not args.global_batch:
+            args.batch = 64
+        bench_extrapolation(args, dist, world, rank, engine, scaling)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     if args.train:
         if "--batch" not in sys.argv and not args.global_batch:
             args.batch = 256

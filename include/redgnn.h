@@ -180,7 +180,7 @@ int rg_tlayer_fwd(const rg_frontier* f, const rg_graph* g, int32_t level, int64_
  * rg_xlayer_fwd is the layer (:186-226) over those edges.  All edges lie in the past, so one direction matrix applies (past_linear):
  * hidden_p = W_past h [N_old, ld], rela_p = W_past rela [n_rela_rows, ld], time_p [n_tab, ld] = W_past time_embed(delta) for
  * delta = 0..n_tab-1; delta(edge, b) = q_time[b] - row_time[data row] (self-loops: q_time[b] - loop_time[b]), clamped to n_tab - 1.
- * Attention as rg_tlayer_fwd.  Forward only. */
+ * Attention as rg_tlayer_fwd.  Its adjoint is rg_xlayer_bwd (below, with rg_tlayer_bwd). */
 int rg_frontier_set_window(rg_frontier* f, const int32_t* win_lo_dev, const int32_t* win_hi_dev, int32_t n_data);
 int rg_xlayer_fwd(const rg_frontier* f, const rg_graph* g, int32_t level, int64_t n_new, const int32_t* q_time,
                   const int32_t* loop_time, const int32_t* row_time, int32_t n_data,
@@ -218,6 +218,21 @@ int rg_tlayer_bwd(const rg_frontier* f, const rg_graph* g, int32_t level, int64_
                   const float* w_alpha, const float* b_alpha, int32_t attn_dim,
                   const float* grad_agg,
                   float* grad_hidden_dir, float* grad_rela_dir, float* grad_time_dir, float* grad_a_s, float* grad_a_r,
+                  float* grad_a_q, float* grad_w_alpha,
+                  void* scratch_dev, size_t scratch_bytes, void* stream);
+
+/* Adjoint of rg_xlayer_fwd (training of the extrapolation setting, Temporal/extrapolation/main.py:296-320 around
+ * model_cuda_new_embedding.py:186-239).  Arguments as rg_xlayer_fwd (the frontier still carries the batch's windows: rg_frontier_set_window).
+ * grad_hidden_p [N_old, ld] and grad_a_s [N_old, ap] are WRITTEN; grad_rela_p [n_rela_rows, ld], grad_time_p [n_tab, ld],
+ * grad_a_r [n_rela_rows, ap], grad_w_alpha [attn_dim] are ACCUMULATED into (caller zero-fills); grad_a_q [B, ap] (may be NULL) is
+ * WRITTEN.  past_linear and the periodic time embedding are differentiated by the caller.  scratch: rg_tlayer_bwd_scratch_bytes(). */
+int rg_xlayer_bwd(const rg_frontier* f, const rg_graph* g, int32_t level, int64_t n_old, const int32_t* q_time,
+                  const int32_t* loop_time, const int32_t* row_time, int32_t n_data,
+                  const float* hidden_p, const float* rela_p, const float* time_p, int32_t n_tab, int32_t d, int32_t ld,
+                  const float* a_s, const float* a_r, const float* a_q, int32_t ap,
+                  const float* w_alpha, const float* b_alpha, int32_t attn_dim,
+                  const float* grad_agg,
+                  float* grad_hidden_p, float* grad_rela_p, float* grad_time_p, float* grad_a_s, float* grad_a_r,
                   float* grad_a_q, float* grad_w_alpha,
                   void* scratch_dev, size_t scratch_bytes, void* stream);
 

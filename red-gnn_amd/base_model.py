@@ -75,12 +75,26 @@ class BaseModel(object):
         batches = _chunks(self.loader.n_train, self.n_batch)[:max_batches]
         started = time.time()
         self.model.train()
+        # the evaluator's captured forwards hold capacity-sized buffers per lane (WN18RR: 1.7 GB each): when they amount to a real
+        # share of the device, give them back before the training epoch allocates its own state
+        held = getattr(self.model, "replay_bytes_held", lambda: 0)()
+        if held and torch.cuda.is_available() and held > torch.cuda.mem_get_info()[0] // 4:
+            self.model.release_replay_buffers()
         losses = []
+        cost_table = None
+        if self.world > 1:
+            # per-query subgraphs differ by far more than 2x (hub subjects): every batch is dealt over the ranks by the
+            # estimated cost of its queries on this epoch's training graph (equal counts), not cut into contiguous blocks
+            cost_table = sharding.entity_costs(self.loader._graph_base, self.n_ent)
         for idx in batches:
-            lo, hi = sharding.shard_slice(len(idx), self.world, self.rank)
+            if cost_table is None:
+                part = np.arange(len(idx))
+            else:
+                part = sharding.split_batch(cost_table[self.loader.train_data[idx, 0]], self.world, self.rank)
+            lo, hi = 0, len(part)
             self.model.zero_grad()
             if hi > lo:
-                triple = self.loader.get_batch(idx[lo:hi])
+                triple = self.loader.get_batch(idx[part])
                 scores = self.model(triple[:, 0], triple[:, 1])
                 tails = torch.as_tensor(triple[:, 2], dtype=torch.long, device=scores.device)
                 # the [n,n] broadcast of the reference's loss spans the whole batch: n_global x this rank's cross entropies
@@ -130,7 +144,8 @@ class BaseModel(object):
             need = _GraphedInference.bytes_needed(self.n_tbatch, n_ent, max(16, _pad4(m.hidden_dim)), pad_attn(m.attn_dim))
         except (AttributeError, ValueError):        # a model without the replayed forward
             need = 0
-        fit = self.EVAL_LANES if need <= 0 else int(_GraphedInference.MAX_BYTES // (3 * need // 2 + 1))
+        budget = _GraphedInference.budget(next(m.parameters()).device)
+        fit = self.EVAL_LANES if need <= 0 else int(budget // (3 * need // 2 + 1))
         lanes = min(self.EVAL_LANES, max(8, n_batches // 8))      # (umls, 28 batches: 8 lanes 364 k queries/s, 16 lanes 305 k)
         while lanes > 1 and lanes > fit:
             lanes //= 2

@@ -8,6 +8,10 @@
 //                                               and is added once; per-edge float atomics on a 2.5 k-row table cost 20x the forward)
 //   g_alpha = <G[o], m_e>  ->  d a_s[s], d a_r[r], d w   exactly as in the static kernel.
 // The direction linears and the attention's three blocks are differentiated by the caller (dense GEMMs).
+// WIN = true is the adjoint of rg_xlayer_fwd (temporal EXTRAPOLATION, Temporal/extrapolation/model_cuda_new_embedding.py:186-239): an
+// edge's time field is its data row, valid for query b inside the row window [win_lo[b], win_hi[b]) only (self-loops, row >= n_data,
+// always); one direction (every edge lies in the past: past_linear), time row = clamp(q_time[b] - row_time[row], 0, n_time - 1)
+// (self-loops: q_time[b] - loop_time[b]); hidden_dir / rela_dir / time_dir are then hidden_p [N_old] / rela_p / time_p [n_time].
 #include "aq_sum.h"
 #include "walk.h"
 
@@ -39,6 +43,12 @@ struct TBwdArgs {
   float* g_time_dir;          // [3 * n_time][ld]
   float* g_ar;
   float* g_w;
+  // WIN
+  const int32_t* win_lo = nullptr;
+  const int32_t* win_hi = nullptr;
+  const int32_t* row_time = nullptr;
+  const int32_t* loop_time = nullptr;
+  int n_data = 0;
 };
 
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -68,10 +78,11 @@ constexpr int TB_BLOCK = 512;
 
 // wide attention MLPs (AP4 >= 4: ICEWS presets use attn_dim = 30) keep 4 x AP4 float4 of per-edge state in registers: 256 VGPRs
 // (2 waves per SIMD; their LDS tables leave room for one workgroup per CU anyway) instead of spilling at 128
-template <int G, int AP4, bool DENSE>
+template <int G, int AP4, bool DENSE, bool WIN>
 __global__ __launch_bounds__(TB_BLOCK, AP4 >= 4 ? 2 : 4) void tlayer_bwd_kernel(TBwdArgs A) {
   extern __shared__ float4 lds[];
   constexpr int BLOCK = TB_BLOCK;
+  constexpr int ND = WIN ? 1 : 3;          // direction rows per source node
   const int nr = A.n_rela_rows;
   float4* stage = lds;                      // [BLOCK] {o -> g_alpha, rela row, alpha, time row * 4 + dir}
   float4* ar_l = stage + BLOCK;             // [nr][AP4]
@@ -105,6 +116,8 @@ __global__ __launch_bounds__(TB_BLOCK, AP4 >= 4 ? 2 : 4) void tlayer_bwd_kernel(
   rg::walk_items<G, DENSE, 1, BLOCK>(A.walk, recs, [&](const int4& R, bool live) {
     const int beg = R.x, end = R.x + rg::walk_len(R), b = R.z, s_node = R.w;
     const int qt = A.q_time[b];
+    int wlo = 0, whi = 0, lt = 0;
+    if constexpr (WIN) { wlo = A.win_lo[b]; whi = A.win_hi[b]; lt = A.loop_time[b]; }
     float4 base[AP4], gas[AP4];
 #pragma unroll
     for (int k = 0; k < AP4; ++k) {
@@ -113,10 +126,10 @@ __global__ __launch_bounds__(TB_BLOCK, AP4 >= 4 ? 2 : 4) void tlayer_bwd_kernel(
       base[k] = make_float4(as.x + aq.x, as.y + aq.y, as.z + aq.z, as.w + aq.w);
       gas[k] = f4zero();
     }
-    float4 hs[3], acc[3];
+    float4 hs[ND], acc[ND];
 #pragma unroll
-    for (int dd = 0; dd < 3; ++dd) {
-      hs[dd] = A.hidden_dir[((int64_t)s_node * 3 + dd) * A.ld4 + lane_c];
+    for (int dd = 0; dd < ND; ++dd) {
+      hs[dd] = A.hidden_dir[((int64_t)s_node * ND + dd) * A.ld4 + lane_c];
       acc[dd] = f4zero();
     }
     const int2* bm_row = A.bm_new + (int64_t)b * A.W;
@@ -124,22 +137,35 @@ __global__ __launch_bounds__(TB_BLOCK, AP4 >= 4 ? 2 : 4) void tlayer_bwd_kernel(
     for (int c0 = beg; c0 < end; c0 += G) {
       // ---- phase 1: one out-edge per lane ---------------------------------------------------------
       const int c = c0 + lane_g;
-      const bool valid = c < end;
+      bool valid = c < end;
       const int cnt = min(G, end - c0);
       int o = 0, r = 0, rrow = 0, tdir = 0;
       float alpha = 0.f;
       float4 zr[AP4];
 #pragma unroll
       for (int k = 0; k < AP4; ++k) zr[k] = f4zero();
+      int erow = 0;
+      if constexpr (WIN) {          // an edge outside the query's window is no edge: it stays in the round as a pad (alpha = 0, row 0)
+        if (valid) {
+          erow = A.out_time[c];
+          valid = erow >= A.n_data || (erow >= wlo && erow < whi);
+        }
+      }
       if (valid) {
         const int2 rt = A.out_rt[c];
         r = rt.x;
         const int2 wp = bm_row[rt.y >> 5];
         o = wp.y + __popc((uint32_t)wp.x & ((1u << (rt.y & 31)) - 1u));
-        const int dt = A.out_time[c] - qt;
-        const int dir = dt > 0 ? 2 : (dt == 0 ? 1 : 0);
-        rrow = dir * nr + r;
-        tdir = (dir * A.n_time + (dt < 0 ? -dt : dt)) * 4 + dir;
+        if constexpr (WIN) {
+          const int delta = qt - (erow >= A.n_data ? lt : A.row_time[erow]);
+          rrow = r;
+          tdir = min(max(delta, 0), A.n_time - 1) * 4;
+        } else {
+          const int dt = A.out_time[c] - qt;
+          const int dir = dt > 0 ? 2 : (dt == 0 ? 1 : 0);
+          rrow = dir * nr + r;
+          tdir = (dir * A.n_time + (dt < 0 ? -dt : dt)) * 4 + dir;
+        }
         float z = b_alpha;
 #pragma unroll
         for (int k = 0; k < AP4; ++k) {
@@ -175,7 +201,8 @@ __global__ __launch_bounds__(TB_BLOCK, AP4 >= 4 ? 2 : 4) void tlayer_bwd_kernel(
         for (int u = 0; u < 2; ++u) {
           const float al = tp[u].z;
           const int dir = __float_as_int(tp[u].w) & 3;
-          const float4 hsel = dir == 0 ? hs[0] : (dir == 1 ? hs[1] : hs[2]);
+          float4 hsel = hs[0];
+          if constexpr (!WIN) hsel = dir == 0 ? hs[0] : (dir == 1 ? hs[1] : hs[2]);
           float dot = 0.f;
           if (row_lane) {
             dot = gv[u].x * (hsel.x + rv[u].x + tv[u].x);
@@ -187,8 +214,8 @@ __global__ __launch_bounds__(TB_BLOCK, AP4 >= 4 ? 2 : 4) void tlayer_bwd_kernel(
           if (lane_g == 0) reinterpret_cast<float*>(&my_stage[k + u])[0] = dot;     // o is consumed: slot reused for g_alpha
           const float4 ag = make_float4(al * gv[u].x, al * gv[u].y, al * gv[u].z, al * gv[u].w);
 #pragma unroll
-          for (int dd = 0; dd < 3; ++dd) {
-            const float m = dir == dd ? 1.f : 0.f;
+          for (int dd = 0; dd < ND; ++dd) {
+            const float m = (WIN || dir == dd) ? 1.f : 0.f;
             acc[dd].x = fmaf(m, ag.x, acc[dd].x); acc[dd].y = fmaf(m, ag.y, acc[dd].y);
             acc[dd].z = fmaf(m, ag.z, acc[dd].z); acc[dd].w = fmaf(m, ag.w, acc[dd].w);
           }
@@ -228,11 +255,11 @@ __global__ __launch_bounds__(TB_BLOCK, AP4 >= 4 ? 2 : 4) void tlayer_bwd_kernel(
     }
     if (live) {
       const int out = rg::walk_out(R, A.walk.n_slots);
-      float4* hrow = out >= 0 ? A.g_hidden_dir + (int64_t)out * 3 * A.ld4 : A.g_hidden_part + (int64_t)(-out - 1) * 3 * A.ld4;
+      float4* hrow = out >= 0 ? A.g_hidden_dir + (int64_t)out * ND * A.ld4 : A.g_hidden_part + (int64_t)(-out - 1) * ND * A.ld4;
       float4* arow = out >= 0 ? A.g_as + (int64_t)out * AP4 : A.g_as_part + (int64_t)(-out - 1) * AP4;
       if (row_lane) {
 #pragma unroll
-        for (int dd = 0; dd < 3; ++dd) hrow[dd * A.ld4 + lane_g] = acc[dd];
+        for (int dd = 0; dd < ND; ++dd) hrow[dd * A.ld4 + lane_g] = acc[dd];
       }
       if (lane_g == 0) {
 #pragma unroll
@@ -312,9 +339,15 @@ struct TKeyArgs {
   int attn_dim, n_rela_rows, n_time, ld4;
   const float4* grad_agg;
   float* g_table;             // g_rela_dir or g_time_dir
+  // WIN
+  const int32_t* win_lo = nullptr;
+  const int32_t* win_hi = nullptr;
+  const int32_t* row_time = nullptr;
+  const int32_t* loop_time = nullptr;
+  int n_data = 0;
 };
 
-template <int G, int AP4, bool BY_TIME>
+template <int G, int AP4, bool BY_TIME, bool WIN>
 __global__ __launch_bounds__(TB_BLOCK, 4) void tkey_kernel(TKeyArgs A) {
   extern __shared__ float4 lds[];
   constexpr int BLOCK = TB_BLOCK;
@@ -342,7 +375,13 @@ __global__ __launch_bounds__(TB_BLOCK, 4) void tkey_kernel(TKeyArgs A) {
   const int lane_c = row_lane ? lane_g : A.ld4 - 1;
 
   rg::walk_items<G, true, 1, BLOCK, true>(A.walk, nullptr, [&](const int4& R, bool live) {
-    const int beg = R.x, end = R.x + rg::walk_len(R), b = R.z, key = R.w;
+    const int beg = R.x, b = R.z, key = R.w;
+    int end = R.x + rg::walk_len(R);
+    int wlo = 0, whi = 0;
+    if constexpr (WIN) {
+      wlo = A.win_lo[b]; whi = A.win_hi[b];
+      if (BY_TIME && key < A.n_data && (key < wlo || key >= whi)) end = beg;      // the whole row lies outside the query's window
+    }
     const int2* old_row = A.bm_old + (int64_t)b * A.W;
     const int2* new_row = A.bm_new + (int64_t)b * A.W;
     const int qt = A.q_time[b];
@@ -363,13 +402,16 @@ __global__ __launch_bounds__(TB_BLOCK, 4) void tkey_kernel(TKeyArgs A) {
         const int2 wp = old_row[ht.x >> 5];
         const uint32_t word = (uint32_t)wp.x, bit = ht.x & 31;
         valid = (word >> bit) & 1u;
+        if constexpr (WIN && !BY_TIME) {
+          if (valid) { const int erow = A.aux[c]; valid = erow >= A.n_data || (erow >= wlo && erow < whi); }
+        }
         if (valid) {
           const int s = wp.y + __popc(word & ((1u << bit) - 1u));
           const int2 wn = new_row[ht.y >> 5];
           o = wn.y + __popc((uint32_t)wn.x & ((1u << (ht.y & 31)) - 1u));
           const int other = A.aux[c];
           const int r = BY_TIME ? other : key;
-          if constexpr (!BY_TIME) { const int dt = other - qt; dir = dt > 0 ? 2 : (dt == 0 ? 1 : 0); }
+          if constexpr (!BY_TIME && !WIN) { const int dt = other - qt; dir = dt > 0 ? 2 : (dt == 0 ? 1 : 0); }
           float z = b_alpha;
 #pragma unroll
           for (int k = 0; k < AP4; ++k) {
@@ -422,14 +464,20 @@ __global__ __launch_bounds__(TB_BLOCK, 4) void tkey_kernel(TKeyArgs A) {
     if (live && row_lane) {
       if constexpr (BY_TIME) {
         if (seen) {
-          const int dt = key - qt;
-          const int dir = dt > 0 ? 2 : (dt == 0 ? 1 : 0);
-          float* gr = A.g_table + ((int64_t)(dir * A.n_time + (dt < 0 ? -dt : dt)) * A.ld4 + lane_g) * 4;
+          int trow;
+          if constexpr (WIN) {
+            trow = min(max(qt - (key >= A.n_data ? A.loop_time[b] : A.row_time[key]), 0), A.n_time - 1);
+          } else {
+            const int dt = key - qt;
+            const int dir = dt > 0 ? 2 : (dt == 0 ? 1 : 0);
+            trow = dir * A.n_time + (dt < 0 ? -dt : dt);
+          }
+          float* gr = A.g_table + ((int64_t)trow * A.ld4 + lane_g) * 4;
           atomicAdd(gr + 0, acc[0].x); atomicAdd(gr + 1, acc[0].y); atomicAdd(gr + 2, acc[0].z); atomicAdd(gr + 3, acc[0].w);
         }
       } else {
 #pragma unroll
-        for (int dd = 0; dd < 3; ++dd)
+        for (int dd = 0; dd < (WIN ? 1 : 3); ++dd)
           if (seen & (1u << dd)) {
             float* gr = A.g_table + ((int64_t)(dd * nr + key) * A.ld4 + lane_g) * 4;
             atomicAdd(gr + 0, acc[dd].x); atomicAdd(gr + 1, acc[dd].y); atomicAdd(gr + 2, acc[dd].z); atomicAdd(gr + 3, acc[dd].w);
@@ -443,7 +491,7 @@ template <int G, int AP4, bool BY_TIME>
 int launch_tkey(const TKeyArgs& A, hipStream_t s) {
   const size_t lds = (size_t)(TB_BLOCK + A.n_rela_rows * AP4 + AP4) * sizeof(float4);
   RG_CHECK(lds <= 160 * 1024, "rg_tlayer_bwd: attention table needs %zu B of LDS (> 160 KiB)", lds);
-  auto kern = tkey_kernel<G, AP4, BY_TIME>;
+  auto kern = A.win_lo ? tkey_kernel<G, AP4, BY_TIME, true> : tkey_kernel<G, AP4, BY_TIME, false>;
   if (lds > 64 * 1024) RG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int grid = rg::walk_grid(A.walk.n_items, TB_BLOCK, G, true, lds <= 80 * 1024 ? 2 : 1, 1);
   if (rg::zero_async(A.walk.queues, RG_QUEUE_BYTES, s)) return 1;
@@ -478,16 +526,17 @@ int launch2(const TBwdArgs& A, int B, const rg_vrows& vr, const int2* bm_old, hi
   size_t lds = (size_t)(TB_BLOCK + 2 * A.n_rela_rows * AP4 + AP4 + (TB_BLOCK / 64) * (AP4 + 1)) * sizeof(float4);
   if (!DENSE) lds += (size_t)TB_BLOCK * sizeof(int4);
   RG_CHECK(lds <= 160 * 1024, "rg_tlayer_bwd: attention tables need %zu B of LDS (> 160 KiB)", lds);
-  auto kern = tlayer_bwd_kernel<G, AP4, DENSE>;
+  auto kern = A.win_lo ? tlayer_bwd_kernel<G, AP4, DENSE, true> : tlayer_bwd_kernel<G, AP4, DENSE, false>;
+  const int nd = A.win_lo ? 1 : 3;
   if (lds > 64 * 1024) RG_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int grid = rg::walk_grid(A.walk.n_items, TB_BLOCK, G, DENSE, lds <= 80 * 1024 ? 2 : 1, 1);
   if (rg::zero_async(A.walk.queues, RG_QUEUE_BYTES, s)) return 1;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(TB_BLOCK), lds, s, A);
   RG_LAUNCH_CHECK();
   if (vr.n_split > 0) {
-    const int64_t threads = (int64_t)B * vr.n_split * (3 * A.ld4 + AP4);
+    const int64_t threads = (int64_t)B * vr.n_split * (nd * A.ld4 + AP4);
     hipLaunchKernelGGL(tbwd_combine_kernel, dim3(rg::ceil_div(threads, 256)), dim3(256), 0, s, vr.split, vr.n_split, vr.n_slots, B,
-                       bm_old, A.W, A.g_hidden_part, A.g_as_part, A.g_hidden_dir, A.g_as, 3 * A.ld4, AP4);
+                       bm_old, A.W, A.g_hidden_part, A.g_as_part, A.g_hidden_dir, A.g_as, nd * A.ld4, AP4);
     RG_LAUNCH_CHECK();
   }
   return 0;
@@ -510,32 +559,44 @@ extern "C" size_t rg_tlayer_bwd_scratch_bytes(const rg_frontier* f, const rg_gra
   return (size_t)f->B * g->out_vr.n_slots * (3 * ld + ap) * sizeof(float) + 512;
 }
 
-extern "C" int rg_tlayer_bwd(const rg_frontier* f, const rg_graph* g, int32_t level, int64_t n_old, const int32_t* q_time,
-                             const float* hidden_dir, const float* rela_dir, const float* time_dir, int32_t d, int32_t ld,
-                             const float* a_s, const float* a_r, const float* a_q, int32_t ap, const float* w_alpha,
-                             const float* b_alpha, int32_t attn_dim, const float* grad_agg, float* grad_hidden_dir,
-                             float* grad_rela_dir, float* grad_time_dir, float* grad_a_s, float* grad_a_r,
-                             float* grad_a_q, float* grad_w_alpha, void* scratch, size_t scratch_bytes, void* stream) {
+namespace {
+struct WinArgs {            // the extrapolation setting's extras; all null / 0 for the interpolation layer
+  const int32_t* loop_time = nullptr;
+  const int32_t* row_time = nullptr;
+  int n_data = 0, n_tab = 0;
+};
+
+int tbwd_impl(const char* who, const rg_frontier* f, const rg_graph* g, int32_t level, int64_t n_old, const int32_t* q_time,
+              const float* hidden_dir, const float* rela_dir, const float* time_dir, int32_t d, int32_t ld,
+              const float* a_s, const float* a_r, const float* a_q, int32_t ap, const float* w_alpha,
+              const float* b_alpha, int32_t attn_dim, const float* grad_agg, float* grad_hidden_dir,
+              float* grad_rela_dir, float* grad_time_dir, float* grad_a_s, float* grad_a_r,
+              float* grad_a_q, float* grad_w_alpha, void* scratch, size_t scratch_bytes, const WinArgs& win, void* stream) {
+  const bool windowed = win.row_time != nullptr;
+  const int nd = windowed ? 1 : 3;
   RG_CHECK(f && g && q_time && hidden_dir && rela_dir && time_dir && a_s && a_r && a_q && w_alpha && b_alpha && grad_agg &&
                grad_hidden_dir && grad_rela_dir && grad_time_dir && grad_a_s && grad_a_r && grad_w_alpha,
-           "rg_tlayer_bwd: NULL argument");
-  RG_CHECK(g->out_time && g->rel_tm && g->time_ht && g->n_time > 0, "rg_tlayer_bwd: the graph has no timestamps (build it with rg_tgraph_create)");
-  RG_CHECK(g->n_ent == f->n_ent, "rg_tlayer_bwd: graph has %d entities, frontier %d", g->n_ent, f->n_ent);
+           "%s: NULL argument", who);
+  RG_CHECK(g->out_time && g->rel_tm && g->time_ht && g->n_time > 0, "%s: the graph has no timestamps (build it with rg_tgraph_create)", who);
+  RG_CHECK(g->n_ent == f->n_ent, "%s: graph has %d entities, frontier %d", who, g->n_ent, f->n_ent);
   RG_CHECK(level >= 1 && level <= f->level && level > f->level - f->n_levels + 1,
-           "rg_tlayer_bwd: level %d not resident (current %d, %d kept)", level, f->level, f->n_levels);
-  RG_CHECK(n_old == f->n_nodes[(level - 1) % f->n_levels], "rg_tlayer_bwd: n_old=%lld but level %d has %lld nodes",
+           "%s: level %d not resident (current %d, %d kept)", who, level, f->level, f->n_levels);
+  RG_CHECK(n_old == f->n_nodes[(level - 1) % f->n_levels], "%s: n_old=%lld but level %d has %lld nodes", who,
            (long long)n_old, level - 1, (long long)f->n_nodes[(level - 1) % f->n_levels]);
-  RG_CHECK(d > 0 && ld >= d && ld % 4 == 0 && ld >= 16 && ld <= 256, "rg_tlayer_bwd: d=%d ld=%d", d, ld);
-  RG_CHECK(attn_dim > 0 && ap >= attn_dim && ap % 4 == 0, "rg_tlayer_bwd: attn_dim=%d ap=%d", attn_dim, ap);
-  RG_CHECK((int64_t)f->B * f->n_ent * 3 < ((int64_t)1 << 31), "rg_tlayer_bwd: 3 * batch * n_ent does not fit int32 row ids");
-  RG_CHECK((int64_t)3 * g->n_time * 4 + 3 < ((int64_t)1 << 31), "rg_tlayer_bwd: n_time too large");
+  RG_CHECK(d > 0 && ld >= d && ld % 4 == 0 && ld >= 16 && ld <= 256, "%s: d=%d ld=%d", who, d, ld);
+  RG_CHECK(attn_dim > 0 && ap >= attn_dim && ap % 4 == 0, "%s: attn_dim=%d ap=%d", who, attn_dim, ap);
+  RG_CHECK((int64_t)f->B * f->n_ent * 3 < ((int64_t)1 << 31), "%s: 3 * batch * n_ent does not fit int32 row ids", who);
+  const int n_time = windowed ? win.n_tab : g->n_time;
+  RG_CHECK((int64_t)3 * n_time * 4 + 3 < ((int64_t)1 << 31), "%s: n_time too large", who);
+  RG_CHECK(!windowed || (f->win_lo && f->win_hi && win.loop_time && win.n_tab > 0 && win.n_data >= 0),
+           "%s: call rg_frontier_set_window first (and pass loop_time, n_tab)", who);
   const size_t need = rg_tlayer_bwd_scratch_bytes(f, g, ld, ap);
-  RG_CHECK(g->out_vr.n_slots == 0 || (scratch && scratch_bytes >= need), "rg_tlayer_bwd: scratch %zu B < required %zu B",
+  RG_CHECK(g->out_vr.n_slots == 0 || (scratch && scratch_bytes >= need), "%s: scratch %zu B < required %zu B", who,
            scratch_bytes, need);
   RG_CHECK((int64_t)f->B * std::max(g->out_vr.n_slots, 1) < ((int64_t)1 << 31) && g->out_vr.n_slots < (1 << 22),
-           "rg_tlayer_bwd: batch * hub segments overflows int32");
+           "%s: batch * hub segments overflows int32", who);
   const int64_t n_items = (int64_t)f->B * g->out_vr.n;
-  RG_CHECK(n_items / 8 + ((int64_t)1 << 26) < ((int64_t)1 << 31), "rg_tlayer_bwd: work space too large for 32-bit queue tickets");
+  RG_CHECK(n_items / 8 + ((int64_t)1 << 26) < ((int64_t)1 << 31), "%s: work space too large for 32-bit queue tickets", who);
   if (n_old == 0) return grad_a_q ? rg::launch_aq_sum(f->bm_of(level - 1), f->W, f->B, f->n_ent, 0, grad_a_s, ap, grad_a_q, (hipStream_t)stream) : 0;
   TBwdArgs A;
   A.walk.n_items = n_items; A.walk.n_vrows = g->out_vr.n; A.walk.n_slots = g->out_vr.n_slots; A.walk.vrows = g->out_vr.rows;
@@ -543,14 +604,15 @@ extern "C" int rg_tlayer_bwd(const rg_frontier* f, const rg_graph* g, int32_t le
   A.out_rt = g->out_rt; A.out_time = g->out_time; A.q_time = q_time;
   A.bm_new = f->bm_of(level); A.W = f->W;
   A.hidden_dir = (const float4*)hidden_dir; A.rela_dir = (const float4*)rela_dir; A.time_dir = (const float4*)time_dir;
-  A.ld4 = ld / 4; A.n_rela_rows = g->n_rela_rows; A.n_time = g->n_time;
+  A.ld4 = ld / 4; A.n_rela_rows = g->n_rela_rows; A.n_time = n_time;
   A.a_s = (const float4*)a_s; A.a_r = (const float4*)a_r; A.a_q = (const float4*)a_q;
   A.w_alpha = w_alpha; A.b_alpha = b_alpha; A.attn_dim = attn_dim;
   A.grad_agg = (const float4*)grad_agg;
   A.g_hidden_dir = (float4*)grad_hidden_dir; A.g_as = (float4*)grad_a_s;
   A.g_rela_dir = grad_rela_dir; A.g_time_dir = grad_time_dir; A.g_ar = grad_a_r; A.g_w = grad_w_alpha;
   A.g_hidden_part = (float4*)scratch;
-  A.g_as_part = (float4*)((char*)scratch + rg::align_up((size_t)f->B * g->out_vr.n_slots * 3 * ld * sizeof(float), 256));
+  A.g_as_part = (float4*)((char*)scratch + rg::align_up((size_t)f->B * g->out_vr.n_slots * nd * ld * sizeof(float), 256));
+  if (windowed) { A.win_lo = f->win_lo; A.win_hi = f->win_hi; A.row_time = win.row_time; A.loop_time = win.loop_time; A.n_data = win.n_data; }
   hipStream_t s = (hipStream_t)stream;
   const bool dense = n_old >= 4 * (int64_t)f->B;
   const int ld4 = ld / 4;
@@ -567,15 +629,43 @@ extern "C" int rg_tlayer_bwd(const rg_frontier* f, const rg_graph* g, int32_t le
   TKeyArgs K;
   K.q_time = q_time; K.bm_old = bm_old; K.bm_new = f->bm_of(level); K.W = f->W;
   K.a_s = (const float4*)a_s; K.a_r = (const float4*)a_r; K.a_q = (const float4*)a_q;
-  K.w_alpha = w_alpha; K.b_alpha = b_alpha; K.attn_dim = attn_dim; K.n_rela_rows = g->n_rela_rows; K.n_time = g->n_time; K.ld4 = ld4;
+  K.w_alpha = w_alpha; K.b_alpha = b_alpha; K.attn_dim = attn_dim; K.n_rela_rows = g->n_rela_rows; K.n_time = n_time; K.ld4 = ld4;
   K.grad_agg = (const float4*)grad_agg;
+  if (windowed) { K.win_lo = f->win_lo; K.win_hi = f->win_hi; K.row_time = win.row_time; K.loop_time = win.loop_time; K.n_data = win.n_data; }
   K.walk.n_slots = 0; K.walk.bm_test = nullptr; K.walk.W = f->W; K.walk.queues = f->queues; f->queues_clean = false;
   K.walk.n_items = (int64_t)f->B * g->rel_vr.n; K.walk.n_vrows = g->rel_vr.n; K.walk.vrows = g->rel_vr.rows;
-  RG_CHECK(K.walk.n_items / 8 + ((int64_t)1 << 26) < ((int64_t)1 << 31), "rg_tlayer_bwd: relation work space too large for 32-bit queue tickets");
+  RG_CHECK(K.walk.n_items / 8 + ((int64_t)1 << 26) < ((int64_t)1 << 31), "%s: relation work space too large for 32-bit queue tickets", who);
   K.ht = g->rel_ht; K.aux = g->rel_tm; K.g_table = grad_rela_dir;
   if (launch_tkey_g<false>(K, ld4, ap / 4, s)) return 1;
   K.walk.n_items = (int64_t)f->B * g->time_vr.n; K.walk.n_vrows = g->time_vr.n; K.walk.vrows = g->time_vr.rows;
-  RG_CHECK(K.walk.n_items / 8 + ((int64_t)1 << 26) < ((int64_t)1 << 31), "rg_tlayer_bwd: time work space too large for 32-bit queue tickets");
+  RG_CHECK(K.walk.n_items / 8 + ((int64_t)1 << 26) < ((int64_t)1 << 31), "%s: time work space too large for 32-bit queue tickets", who);
   K.ht = g->time_ht; K.aux = g->time_rel; K.g_table = grad_time_dir;
   return launch_tkey_g<true>(K, ld4, ap / 4, s);
+}
+}  // namespace
+
+extern "C" int rg_tlayer_bwd(const rg_frontier* f, const rg_graph* g, int32_t level, int64_t n_old, const int32_t* q_time,
+                             const float* hidden_dir, const float* rela_dir, const float* time_dir, int32_t d, int32_t ld,
+                             const float* a_s, const float* a_r, const float* a_q, int32_t ap, const float* w_alpha,
+                             const float* b_alpha, int32_t attn_dim, const float* grad_agg, float* grad_hidden_dir,
+                             float* grad_rela_dir, float* grad_time_dir, float* grad_a_s, float* grad_a_r,
+                             float* grad_a_q, float* grad_w_alpha, void* scratch, size_t scratch_bytes, void* stream) {
+  return tbwd_impl("rg_tlayer_bwd", f, g, level, n_old, q_time, hidden_dir, rela_dir, time_dir, d, ld, a_s, a_r, a_q, ap, w_alpha, b_alpha,
+                   attn_dim, grad_agg, grad_hidden_dir, grad_rela_dir, grad_time_dir, grad_a_s, grad_a_r, grad_a_q, grad_w_alpha, scratch,
+                   scratch_bytes, WinArgs(), stream);
+}
+
+// Adjoint of rg_xlayer_fwd (temporal extrapolation; see the header comment): grad_hidden_p [N_old, ld], grad_rela_p [n_rela_rows, ld],
+// grad_time_p [n_tab, ld] (the last two zero-initialised by the caller, added into), the attention gradients as rg_tlayer_bwd.
+extern "C" int rg_xlayer_bwd(const rg_frontier* f, const rg_graph* g, int32_t level, int64_t n_old, const int32_t* q_time,
+                             const int32_t* loop_time, const int32_t* row_time, int32_t n_data, const float* hidden_p, const float* rela_p,
+                             const float* time_p, int32_t n_tab, int32_t d, int32_t ld, const float* a_s, const float* a_r, const float* a_q,
+                             int32_t ap, const float* w_alpha, const float* b_alpha, int32_t attn_dim, const float* grad_agg,
+                             float* grad_hidden_p, float* grad_rela_p, float* grad_time_p, float* grad_a_s, float* grad_a_r, float* grad_a_q,
+                             float* grad_w_alpha, void* scratch, size_t scratch_bytes, void* stream) {
+  RG_CHECK(loop_time && row_time, "rg_xlayer_bwd: NULL argument");
+  WinArgs w;
+  w.loop_time = loop_time; w.row_time = row_time; w.n_data = n_data; w.n_tab = n_tab;
+  return tbwd_impl("rg_xlayer_bwd", f, g, level, n_old, q_time, hidden_p, rela_p, time_p, d, ld, a_s, a_r, a_q, ap, w_alpha, b_alpha, attn_dim,
+                   grad_agg, grad_hidden_p, grad_rela_p, grad_time_p, grad_a_s, grad_a_r, grad_a_q, grad_w_alpha, scratch, scratch_bytes, w, stream);
 }

@@ -35,11 +35,21 @@ def _require_gpu(device):
     return device
 
 
+_GRAPH_SERIAL = [0]
+
+
+def _next_serial():
+    _GRAPH_SERIAL[0] += 1
+    return _GRAPH_SERIAL[0]
+
+
 class Graph:
     """Device-resident KG (inverse + identity rows added, CSR by head and by tail).
-    Replaces load_data.py:69-81 (double_triple + load_graph)."""
+    Replaces load_data.py:69-81 (double_triple + load_graph).  ``serial`` is unique per object for the life of the process (caches key
+    on it: id() of a collected graph can come back)."""
 
     def __init__(self, n_ent, n_rel, triples, add_inverse=True, device="cuda"):
+        self.serial = _next_serial()
         self.device = _require_gpu(device)
         trip = np.ascontiguousarray(np.asarray(triples, dtype=np.int32).reshape(-1, 3))
         self.n_ent, self.n_rel = int(n_ent), int(n_rel)
@@ -55,6 +65,7 @@ class Graph:
         """The same graph built on the device from a device int32 [n,3] tensor (rg_graph_create_device): the per-epoch rebuild of
         shuffle_train without a host round trip of the triples."""
         self = cls.__new__(cls)
+        self.serial = _next_serial()
         self.device = _require_gpu(triples_dev.device)
         assert triples_dev.dtype == torch.int32 and triples_dev.dim() == 2 and triples_dev.shape[1] == 3
         trip = triples_dev.contiguous()
@@ -106,6 +117,7 @@ class TemporalGraph(Graph):
 
     def __init__(self, n_ent, n_rela_rows, n_time, quads, device="cuda", exclude=None):
         """``exclude``: row indices of ``quads`` to leave out (the training mode's np.delete, done while the rows are read)."""
+        self.serial = _next_serial()
         self.device = _require_gpu(device)
         q = quads if (isinstance(quads, np.ndarray) and quads.dtype == np.int32 and quads.flags.c_contiguous and quads.ndim == 2) \
             else np.ascontiguousarray(np.asarray(quads, dtype=np.int32).reshape(-1, 4))
@@ -382,10 +394,17 @@ def xlayer_fwd(frontier, graph, level, n_new, q_time, loop_time, row_time, n_dat
     agg = torch.empty((n_new, ld), dtype=torch.float32, device=hidden_p.device)
     nbytes = _lib.lib().rg_layer_fwd_scratch_bytes(frontier.handle, graph.handle, ld)
     scratch = frontier.scratch(nbytes)
+    ev = None
+    if KERNEL_EVENTS is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
     _lib.check(_lib.lib().rg_xlayer_fwd(frontier.handle, graph.handle, level, n_new, _lib.ptr(q_time), _lib.ptr(loop_time), _lib.ptr(row_time),
                                         int(n_data), _lib.ptr(hidden_p), _lib.ptr(rela_p), _lib.ptr(time_p), time_p.shape[0], d, ld,
                                         _lib.ptr(a_s), _lib.ptr(a_r), _lib.ptr(a_q), ap, _lib.ptr(w_alpha), _lib.ptr(b_alpha), attn_dim,
                                         _lib.ptr(agg), _lib.ptr(scratch), nbytes, _lib.stream_ptr()))
+    if ev is not None:
+        ev[1].record()
+        KERNEL_EVENTS.append((ev[0], ev[1], frontier.n_edges, n_new))
     return agg
 
 
@@ -441,6 +460,29 @@ def tlayer_bwd(frontier, graph, level, n_old, q_time, hidden_dir, rela_dir, time
                                         _lib.ptr(g_rd), _lib.ptr(g_td), _lib.ptr(g_as), _lib.ptr(g_ar), _lib.ptr(g_aq), _lib.ptr(g_w),
                                         _lib.ptr(scratch), nbytes, _lib.stream_ptr()))
     return g_hd, g_rd, g_td, g_as, g_ar, g_aq, g_w
+
+
+def xlayer_bwd(frontier, graph, level, n_old, q_time, loop_time, row_time, n_data, hidden_p, rela_p, time_p, d, a_s, a_r, a_q, w_alpha,
+               b_alpha, attn_dim, grad_agg):
+    """Adjoint of xlayer_fwd (rg_xlayer_bwd).  Returns grads of (hidden_p [n_old, ld], rela_p, time_p, a_s, a_r, a_q, w_alpha)."""
+    ld, ap = hidden_p.shape[1], a_s.shape[1]
+    grad_agg = grad_agg.contiguous()
+    dev = hidden_p.device
+    g_hp = torch.empty_like(hidden_p)
+    g_as = torch.empty_like(a_s)
+    g_rp = torch.zeros_like(rela_p)
+    g_tp = torch.zeros_like(time_p)
+    g_ar = torch.zeros_like(a_r)
+    g_aq = torch.empty_like(a_q)
+    g_w = torch.zeros(attn_dim, dtype=torch.float32, device=dev)
+    nbytes = _lib.lib().rg_tlayer_bwd_scratch_bytes(frontier.handle, graph.handle, ld, ap)
+    scratch = frontier.scratch(nbytes)
+    _lib.check(_lib.lib().rg_xlayer_bwd(frontier.handle, graph.handle, level, n_old, _lib.ptr(q_time), _lib.ptr(loop_time), _lib.ptr(row_time),
+                                        int(n_data), _lib.ptr(hidden_p), _lib.ptr(rela_p), _lib.ptr(time_p), time_p.shape[0], d, ld,
+                                        _lib.ptr(a_s), _lib.ptr(a_r), _lib.ptr(a_q), ap, _lib.ptr(w_alpha), _lib.ptr(b_alpha), attn_dim,
+                                        _lib.ptr(grad_agg), _lib.ptr(g_hp), _lib.ptr(g_rp), _lib.ptr(g_tp), _lib.ptr(g_as), _lib.ptr(g_ar),
+                                        _lib.ptr(g_aq), _lib.ptr(g_w), _lib.ptr(scratch), nbytes, _lib.stream_ptr()))
+    return g_hp, g_rp, g_tp, g_as, g_ar, g_aq, g_w
 
 
 _BLAS_CHOICE = [None]

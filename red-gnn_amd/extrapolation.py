@@ -1,4 +1,4 @@
-"""T_RED_GNN for temporal EXTRAPOLATION (forecasting) on the HIP path - inference.
+"""T_RED_GNN for temporal EXTRAPOLATION (forecasting) on the HIP path - inference and training.
 
 Mirrors Temporal/extrapolation/model_cuda_new_embedding.py:57-265 (the reference's ``T_RED_GNN`` with the periodic time embedding):
 parameters ``rela_embed_layer.{i}`` [n_rel + 2, d], ``attention_1_layer.{i}`` (3d -> a, no bias), ``attention_2_layer.{i}`` (a -> 1, no
@@ -24,7 +24,34 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import engine
-from .models import pad_attn
+from .models import pad_attn, tall_linear
+
+
+class _XAggregate(torch.autograd.Function):
+    """agg = rg_xlayer_fwd(...);  backward = rg_xlayer_bwd(...).  The frontier keeps the batch's row windows until the backward has run
+    (the lease holds it; T_RED_GNN.forward clears the windows only on the inference path)."""
+
+    @staticmethod
+    def forward(ctx, hidden_p, rela_p, time_p, a_s, a_r, a_q, w_alpha, b_alpha, lease, graph, level, n_new, q_time, loop_time, row_time,
+                n_data, d, attn_dim):
+        hidden_p, rela_p, time_p, a_s, a_r, a_q, w_alpha = (t.contiguous() for t in (hidden_p, rela_p, time_p, a_s, a_r, a_q, w_alpha))
+        agg = engine.xlayer_fwd(lease.frontier, graph, level, n_new, q_time, loop_time, row_time, n_data, hidden_p, rela_p, time_p, d,
+                                a_s, a_r, a_q, w_alpha, b_alpha, attn_dim)
+        ctx.save_for_backward(hidden_p, rela_p, time_p, a_s, a_r, a_q, w_alpha, b_alpha, q_time, loop_time, row_time)
+        ctx.misc = (lease, graph, level, n_data, d, attn_dim)
+        return agg
+
+    @staticmethod
+    def backward(ctx, grad_agg):
+        hidden_p, rela_p, time_p, a_s, a_r, a_q, w_alpha, b_alpha, q_time, loop_time, row_time = ctx.saved_tensors
+        lease, graph, level, n_data, d, attn_dim = ctx.misc
+        lease.check()
+        g = engine.xlayer_bwd(lease.frontier, graph, level, a_s.shape[0], q_time, loop_time, row_time, n_data, hidden_p, rela_p, time_p, d,
+                              a_s, a_r, a_q, w_alpha, b_alpha, attn_dim, grad_agg)
+        if level == 1:
+            lease.release()
+        return (g[0], g[1], g[2], g[3], g[4], g[5], g[6].view_as(w_alpha)) + (None,) * 11
+
 
 WINDOW = 120        # model_cuda_new_embedding.py:168: begin_time = cur_t - 120
 
@@ -129,9 +156,11 @@ class T_RED_GNN(nn.Module):
         win_lo, win_hi = to32(off[begin]), to32(off[cur_t])                         # :171 dataset[offset[begin]:offset[cur_t]]
         q_time, loop_time = to32(cur_t), to32(begin)                                # self-loops carry time begin * granularity (:172)
         q_rel = torch.as_tensor(rel, dtype=torch.int64).to(device)
-        fr = self._frontiers.get(self.n_ent, n, 2, device)
+        with_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        fr = self._frontiers.get(self.n_ent, n, self.n_layer + 1 if with_grad else 2, device)
         fr.set_window(win_lo, win_hi, self.n_data)
         fr.reset(to32(src))
+        lease = engine.FrontierLease(fr) if with_grad else None
         d, a = self.hidden_dim, self.attn_dim
         ld, ap = max(16, _pad4(d)), pad_attn(a)
         padc = lambda t: F.pad(t, (0, ld - d)) if ld != d else t
@@ -143,32 +172,38 @@ class T_RED_GNN(nn.Module):
         oldest = np.where(lo_h < hi_h, self._row_time_host[np.minimum(lo_h, self.n_data - 1)], begin) if self.n_data else begin
         n_tab = int(np.maximum(cur_t - oldest, cur_t - begin).max()) + 1 if n else 1
         deltas = torch.arange(n_tab, dtype=torch.float32, device=device)
-        time_p = padc(F.linear(self.time_embed(deltas.view(-1, 1)).squeeze(1), w_past)).contiguous()     # W_past time_embed(delta)  (:201,205)
         hidden = torch.zeros((n, d), device=device)
         zero_b = torch.zeros(1, device=device)
         n_edges = []
-        with torch.no_grad():
+        with torch.set_grad_enabled(with_grad):
+            time_p = padc(F.linear(self.time_embed(deltas.view(-1, 1)).squeeze(1), w_past)).contiguous()     # W_past time_embed(delta)  (:201,205)
             for i in range(self.n_layer):
                 rela, w1, w2 = self.rela_embed_layer[i].weight, self.attention_1_layer[i].weight, self.attention_2_layer[i].weight
                 n_new, n_e, n_old = fr.expand(self.graph)
                 n_edges.append(n_e)
-                a_s = F.linear(hidden, pad_rows(w1[:, :d])).contiguous()                          # attention_1 on [h_s | rel | rel_q] (:207-208)
+                a_s = tall_linear(hidden, pad_rows(w1[:, :d])).contiguous()                       # attention_1 on [h_s | rel | rel_q] (:207-208)
                 a_r = F.linear(rela, pad_rows(w1[:, d:2 * d])).contiguous()
                 a_q = F.linear(rela[q_rel], pad_rows(w1[:, 2 * d:])).contiguous()
-                hidden_p = padc(F.linear(hidden, w_past)).contiguous()                            # W_past (h + r + tau) = W_past h + ... (:203-205)
+                hidden_p = padc(tall_linear(hidden, w_past)).contiguous()                         # W_past (h + r + tau) = W_past h + ... (:203-205)
                 rela_p = padc(F.linear(rela, w_past)).contiguous()
-                agg = engine.xlayer_fwd(fr, self.graph, fr.level, n_new, q_time, loop_time, self.row_time, self.n_data, hidden_p, rela_p,
-                                        time_p, d, a_s, a_r, a_q, w2.reshape(-1).contiguous(), zero_b, a)
+                w_alpha = w2.reshape(-1).contiguous()
+                if with_grad:
+                    agg = _XAggregate.apply(hidden_p, rela_p, time_p, a_s, a_r, a_q, w_alpha, zero_b, lease, self.graph, fr.level, n_new,
+                                            q_time, loop_time, self.row_time, self.n_data, d, a)
+                else:
+                    agg = engine.xlayer_fwd(fr, self.graph, fr.level, n_new, q_time, loop_time, self.row_time, self.n_data, hidden_p, rela_p,
+                                            time_p, d, a_s, a_r, a_q, w_alpha, zero_b, a)
                 hidden = self.act(agg[:, :d])                                                     # :238-239
             nodes, _, _ = fr.nodes(want_prev=False, want_old_new=False)
-            result = F.linear(hidden, self.linear_classifier.weight, self.linear_classifier.bias).reshape(-1)   # :244
+            result = tall_linear(hidden, self.linear_classifier.weight, self.linear_classifier.bias).reshape(-1)   # :244
             b_idx = nodes[:, 0].long()
             score_all = torch.zeros(n * self.n_ent, device=device).index_copy(0, b_idx * self.n_ent + nodes[:, 1].long(), result)
             # scatter_softmax(result, cur_entity[:, 0]) (:248): per-query softmax over the visited entities
-            row_max = torch.full((n,), float("-inf"), device=device).scatter_reduce(0, b_idx, result, "amax")
+            row_max = torch.full((n,), float("-inf"), device=device).scatter_reduce(0, b_idx, result.detach(), "amax")
             ex = torch.exp(result - row_max[b_idx])
             soft = ex / torch.zeros(n, device=device).index_add(0, b_idx, ex)[b_idx]
-        fr.set_window(None, None, 0)
+        if not with_grad:
+            fr.set_window(None, None, 0)         # (a training forward's frontier keeps its windows for the backward: every reset sets them anew)
         self.last_stats = dict(n_edges=n_edges, n_nodes=int(nodes.shape[0]))
         return score_all.view(n, self.n_ent), (soft, nodes.long().cpu().numpy())
 

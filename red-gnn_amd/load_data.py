@@ -103,7 +103,9 @@ class DataLoader:
             fil = [filters[k] for k in q]
             ids.update({split + "_q": np.asarray(q, dtype=np.int64).reshape(-1, 2), split + "_ans_ptr": ptr(a), split + "_ans_idx": cat(a),
                         split + "_filt_ptr": ptr(fil), split + "_filt_idx": cat(fil)})
-        np.savez_compressed(path, **ids)
+        tmp = "%s.%d.tmp.npz" % (path, os.getpid())           # ranks may parse concurrently: write aside, then rename into place
+        np.savez_compressed(tmp, **ids)
+        os.replace(tmp, path)
         self._filters = defaultdict(set)                    # (the text parse above filled it; the binary path starts clean)
         return ids
 
@@ -148,6 +150,7 @@ class DataLoader:
     def load_graph(self, base_triples):
         if self._graph is not None:
             self._graph.close()
+        self.__dict__.pop("_graph_perm", None)       # a permutation left by shuffle_train belongs to ITS triples, not to these
         self._graph, self._graph_base = None, np.asarray(base_triples, dtype=np.int64).reshape(-1, 3)
         self.n_fact = 2 * len(self._graph_base) + self.n_ent
 
@@ -161,7 +164,7 @@ class DataLoader:
     def graph(self):
         if self._graph is None:
             perm = self.__dict__.pop("_graph_perm", None)
-            if perm is not None and torch.cuda.is_available():
+            if perm is not None and torch.device(self.device).type == "cuda" and torch.cuda.is_available():
                 # shuffle_train's re-split on the device: the triples of facts + train live there (uploaded once); an epoch moves
                 # only the permutation, and rg_graph_create_device builds the CSRs where they are used
                 all_dev = self.__dict__.get("_all_triple_dev")

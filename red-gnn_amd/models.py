@@ -227,6 +227,16 @@ class _GraphedInference:
 
     MAX_BYTES = 64 << 30      # of the 288 GB: capacity-sized replay buffers of all lanes and batch shapes together may take twice this
 
+    @classmethod
+    def budget(cls, device):
+        """Bytes one captured forward may take: MAX_BYTES, or a quarter of what is free on the device right now if that is less (a
+        smaller or shared device, training state resident beside the evaluator's buffers)."""
+        try:
+            free, _ = torch.cuda.mem_get_info(device)
+        except Exception:
+            return cls.MAX_BYTES
+        return min(cls.MAX_BYTES, free // 4)
+
     def __init__(self, model, graph, n, device, hints):
         self.model, self.graph, self.n, self.hints = model, graph, n, hints
         d, a = model.hidden_dim, model.attn_dim
@@ -421,7 +431,7 @@ class RED_GNN_trans(nn.Module):
         Returns None when this call should run eagerly: the first two calls of a shape (the eager run also provides the
         per-hop sizes that pick the kernels' walks), or shapes whose full-grid buffers would be too large."""
         # one captured graph (with its own full-grid buffers) per stream: the evaluator's lanes replay concurrently
-        key = (id(graph), n, str(device), torch.cuda.current_stream(device).cuda_stream, self.dense_precision)
+        key = (graph.serial, n, str(device), torch.cuda.current_stream(device).cuda_stream, self.dense_precision)
         g = self._graphed.get(key)
         if g is not None and g.key_ptr != self.W_final.weight.data_ptr():        # parameters were re-allocated (.to(), ...)
             g = None
@@ -430,7 +440,8 @@ class RED_GNN_trans(nn.Module):
             ld, ap = max(16, _pad4(self.hidden_dim)), pad_attn(self.attn_dim)
             seen = self._seen.get(key, 0)
             self._seen[key] = seen + 1
-            if seen < 2 or _GraphedInference.bytes_needed(n, graph.n_ent, ld, ap) > _GraphedInference.MAX_BYTES:
+            budget = _GraphedInference.budget(device)
+            if seen < 2 or _GraphedInference.bytes_needed(n, graph.n_ent, ld, ap) > budget:
                 self._pending_key = key          # the eager run that follows records its per-hop sizes under this key
                 return None
             hints = self._hints.get(key) or [(n * graph.n_ent, 1, None)] * self.n_layer      # (node count, walk, edge count) per hop
@@ -440,8 +451,8 @@ class RED_GNN_trans(nn.Module):
             # memory budget for the capacity-sized buffers
             need = _GraphedInference.bytes_needed(n, graph.n_ent, ld, ap)
             held = sum(_GraphedInference.bytes_needed(v.n, v.graph.n_ent, v.ld, v.ap) for v in self._graphed.values())
-            if len(self._graphed) >= 80 or held + need > 2 * _GraphedInference.MAX_BYTES:
-                self._graphed.clear()
+            if len(self._graphed) >= 80 or held + need > 2 * budget:
+                self.release_replay_buffers()
             try:
                 g = self._graphed[key] = _GraphedInference(self, graph, n, device, hints)
             except Exception as exc:      # capture refused (memory, a runtime that cannot capture here, ...): keep the eager HIP path
@@ -454,6 +465,20 @@ class RED_GNN_trans(nn.Module):
         scores = g.run(q_sub, q_rel)
         self._last_stats = g.stats
         return scores
+
+    def replay_bytes_held(self):
+        return sum(_GraphedInference.bytes_needed(v.n, v.graph.n_ent, v.ld, v.ap) for v in self._graphed.values())
+
+    def release_replay_buffers(self):
+        """Drop every captured forward with its capacity-sized buffers (and the bookkeeping keyed like them).  Other lanes' replays
+        may still be in flight on their streams: the device is drained first - destroying an executing graph is not known to be safe."""
+        if self._graphed:
+            torch.cuda.synchronize()
+        self._graphed.clear()
+        self._seen.clear()
+        self._hints.clear()
+        self._graph_failed.clear()
+        self._pending_key = None
 
     def _forward_inference(self, fr, graph, q_sub, q_rel, n, device, trace):
         """The same forward with no autograd graph: per layer one expansion, one fused message-passing

@@ -68,6 +68,12 @@ def query_costs(base_triples, n_ent, subs, hops=2):
     ``base_triples`` (inverse and identity rows added, load_data.py:69-79): hop 1 = out-degree of the subject, hop 2 = sum of the
     out-degrees of its neighbours (itself included through the identity row).  Host numpy, O(|KG|)."""
     import numpy as np
+    return entity_costs(base_triples, n_ent, hops)[np.asarray(subs, dtype=np.int64)]
+
+
+def entity_costs(base_triples, n_ent, hops=2):
+    """query_costs for every entity as the query subject: one table per graph (the trainer builds it once per epoch)."""
+    import numpy as np
     t = np.asarray(base_triples, dtype=np.int64).reshape(-1, 3)
     heads = np.concatenate([t[:, 0], t[:, 2], np.arange(n_ent)])
     tails = np.concatenate([t[:, 2], t[:, 0], np.arange(n_ent)])
@@ -79,7 +85,16 @@ def query_costs(base_triples, n_ent, subs, hops=2):
         np.add.at(nxt, heads, reach[tails])
         reach = nxt
         cost = cost + reach
-    return cost[np.asarray(subs, dtype=np.int64)]
+    return cost
+
+
+def split_batch(costs, world, rank):
+    """Positions of one batch that rank ``rank`` of ``world`` runs: equal counts, near-equal estimated cost (shard_balanced).
+    Every rank computes the same split from the same costs; the union over ranks is the batch, the parts are disjoint."""
+    import numpy as np
+    if world == 1:
+        return np.arange(len(costs))
+    return np.asarray(shard_balanced(costs, world)[rank], dtype=np.int64)
 
 
 def gather_scores(local_scores, dist, sizes=None, async_op=False):

@@ -19,6 +19,9 @@ SHAPES = {
     "C3": dict(n_ent=40_000, n_rel=11, n_triples=93_000, n_layer=5, hidden_dim=64, attn_dim=5),
     "C4": dict(n_ent=15_000, n_rel=237, n_triples=310_000, n_layer=4, hidden_dim=128, attn_dim=5),
     "C5": dict(n_ent=7_000, n_rel=230, n_triples=90_000, n_layer=5, hidden_dim=64, attn_dim=30, n_time=365),
+    # the same ICEWS14 shape for the EXTRAPOLATION setting (Temporal/extrapolation/main.py: DP_steps = 3, reversed relations
+    # added, hourly stamps at a granularity of 24): 2 x 90 k time-sorted rows, 460 relations + the self-loop relation
+    "X": dict(n_ent=7_000, n_rel=230, n_triples=90_000, n_layer=3, hidden_dim=64, attn_dim=30, n_time=365, time_granularity=24),
 }
 
 
@@ -116,6 +119,19 @@ def make_temporal_kg(n_ent, n_rel_base, n_time_base, n_quads, seed=1234):
 def make_temporal_shape(name="C5", seed=1234):
     s = SHAPES[name]
     return make_temporal_kg(s["n_ent"], s["n_rel"], s.get("n_time", 365), s["n_triples"], seed=seed)
+
+
+def make_extrapolation_shape(name="X", seed=1234):
+    """(data int64 [2 n, 4] = (subject, relation, object, time) sorted by time with the reversed rows added (relation + n_rel), n_ent,
+    n_rel_true = 2 n_rel, time_granularity): the layout of the reference's contents.data (Temporal/extrapolation/utils.py Data)."""
+    s = SHAPES[name]
+    tkg = make_temporal_kg(s["n_ent"], s["n_rel"], s.get("n_time", 365), s["n_triples"], seed=seed)
+    gran = s.get("time_granularity", 24)
+    rows = tkg.quads[:2 * tkg.n_base].astype(np.int64)                 # forward quads + their inverses (identity rows are per query)
+    rng = np.random.default_rng(seed + 1)
+    rows[:, 3] = rows[:, 3] * gran + np.tile(rng.integers(0, gran, tkg.n_base), 2)      # a forward row and its reverse share the stamp
+    rows = rows[np.argsort(rows[:, 3], kind="stable")]
+    return rows, s["n_ent"], 2 * s["n_rel"], gran
 
 
 def write_task_dir(kg, task_dir):

@@ -716,6 +716,115 @@ def test_temporal_extrapolation_vs_oracle(d, a, act, n_layer, B):
     assert r1[1] == r2[1] and np.mean(r1[0] != r2[0]) <= 0.1 and np.mean(r1[2] != r2[2]) <= 0.1       # (near-ties may swap)
 
 
+def _extrap_setup(n_ent, n_rel, data, d, a, act, n_layer, seed=3):
+    from red_gnn_amd import extrapolation as X
+
+    class P:
+        pass
+
+    p = P()
+    p.n_ent, p.n_rel, p.data, p.time_granularity, p.hidden_dim, p.attn_dim, p.n_layer, p.act, p.device = n_ent, n_rel, data, 24, d, a, n_layer, act, "cuda"
+    torch.manual_seed(seed)
+    return X.T_RED_GNN(p).cuda()
+
+
+@pytest.mark.parametrize("d,a,act,n_layer,B", [(32, 5, "tanh", 3, 9), (64, 30, "relu", 2, 24), (20, 3, "idd", 2, 3)])
+def test_temporal_extrapolation_training_step_vs_oracle_autograd(d, a, act, n_layer, B):
+    """SURVEY 8 f4, training (Temporal/extrapolation/main.py:296-320 around model_cuda_new_embedding.py:135-261): the windowed layer's
+    adjoint rg_xlayer_bwd - scores, the loss of main.py:303-308 and the gradient of EVERY parameter the forward uses against torch
+    autograd through the oracle's restatement (parity UNPINNED, as the forward: the model file cannot be imported here).  Queries
+    older and younger than the window, days without rows, hub objects, duplicate rows, cut hub rows."""
+    rng = np.random.default_rng(7 * d + B)
+    n_ent, n_rel, n = 150, 6, 6000
+    days = np.sort(rng.choice(np.delete(np.arange(220), [0, 50, 51, 120]), n))
+    w = 1.0 / np.arange(1, n_ent + 1); w /= w.sum()
+    data = np.stack([rng.choice(n_ent, n, p=w[::-1]), rng.integers(0, n_rel, n), rng.choice(n_ent, n, p=w), days * 24 + rng.integers(0, 24, n)], 1)
+    data = data[np.argsort(data[:, 3], kind="stable")]
+    data[10:14] = data[9]
+    model = _extrap_setup(n_ent, n_rel, data, d, a, act, n_layer).train()
+    q = data[np.sort(rng.choice(np.arange(30, n), B, replace=False))]
+
+    class Q:
+        src_idx, rel_idx, ts = q[:, 0], q[:, 1], q[:, 3]
+
+    target = torch.as_tensor(q[:, 2], dtype=torch.long)
+    score, (soft, ents) = model(Q)
+    loss = F.nll_loss(torch.log(F.softmax(score, dim=1) + 1e-12), target.cuda())
+    loss.backward()
+    sd = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point) for k, v in model.state_dict().items()}
+    ref_s, ref_soft, ref_ents = orc.extrap_forward(sd, data, orc.get_time_offset_list(data, 24), 24, n_ent, n_rel, q[:, 0], q[:, 1], q[:, 3], n_layer, act)
+    ref_loss = F.nll_loss(torch.log(F.softmax(ref_s, dim=1) + 1e-12), target)
+    ref_loss.backward()
+    assert np.array_equal(ents, ref_ents)
+    np.testing.assert_allclose(score.detach().cpu().numpy(), ref_s.detach().numpy(), rtol=RTOL, atol=ATOL_H)
+    assert abs(loss.item() - ref_loss.item()) < 2e-5 * max(1.0, abs(ref_loss.item()))
+    used = 0
+    for k, v in model.named_parameters():
+        ref = sd[k].grad
+        if ref is None:                      # parameters the reference constructs but its forward never reads
+            assert v.grad is None or not v.grad.any(), k
+            continue
+        used += 1
+        ref = ref.numpy()
+        np.testing.assert_allclose(v.grad.cpu().numpy(), ref, rtol=2e-3, atol=2e-5 * max(1.0, float(np.abs(ref).max())), err_msg=k)
+    assert used >= 4 * n_layer + 4
+    # a second step on another batch reuses the frontier (its windows are set anew) - and an inference call in between clears them
+    model.zero_grad()
+    with torch.no_grad():
+        model(Q)
+    score2, _ = model(Q)
+    assert torch.equal(score2, score)
+
+
+def test_temporal_extrapolation_icews14_shape():
+    """The extrapolation path at the ICEWS14 shape (7 k entities, 230 + 230 relations, 365 days of hourly stamps, 180 k time-sorted rows)
+    with real 120-day windows: forward vs the oracle on queries late in the year (full windows), properties at batch size 32 (every
+    query's visited set holds its subject, softmax sums to one, scores of unvisited entities are exact zeros, edge counts grow with
+    the hop), and one training step with finite gradients."""
+    from red_gnn_amd.synthetic import SHAPES, make_extrapolation_shape
+    data, n_ent, n_rel, gran = make_extrapolation_shape("X")
+    sh = SHAPES["X"]
+    assert data.shape == (180_000, 4) and n_ent == 7000 and n_rel == 460 and np.all(np.diff(data[:, 3]) >= 0)
+    model = _extrap_setup(n_ent, n_rel, data, sh["hidden_dim"], sh["attn_dim"], "relu", sh["n_layer"]).eval()
+    rng = np.random.default_rng(5)
+    late = np.flatnonzero(data[:, 3] // gran >= 200)
+    q = data[np.sort(rng.choice(late, 32, replace=False))]
+
+    class Q:
+        src_idx, rel_idx, ts = q[:, 0], q[:, 1], q[:, 3]
+
+    with torch.no_grad():
+        score, (soft, ents) = model(Q)
+    e = model.last_stats["n_edges"]
+    assert e[0] < e[1] < e[2] and e[2] > 1e6
+    b = torch.as_tensor(ents[:, 0]).cuda()
+    assert torch.allclose(torch.zeros(32, device="cuda").index_add(0, b, soft), torch.ones(32, device="cuda"), atol=1e-5)
+    visited = torch.zeros(32, n_ent, dtype=torch.bool)
+    visited[ents[:, 0], ents[:, 1]] = True
+    assert bool(visited[np.arange(32), q[:, 0]].all()) and not bool(score.cpu()[~visited].any())
+    # three of the queries against the oracle (its per-query python loop over the 60 k-row windows is the slow part)
+    sel = [0, 13, 31]
+
+    class Q3:
+        src_idx, rel_idx, ts = q[sel, 0], q[sel, 1], q[sel, 3]
+
+    with torch.no_grad():
+        s3, (soft3, ents3) = model(Q3)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    ref_s, ref_soft, ref_ents = orc.extrap_forward(sd, data, orc.get_time_offset_list(data, gran), gran, n_ent, n_rel, q[sel, 0], q[sel, 1], q[sel, 3],
+                                                   sh["n_layer"], "relu")
+    assert np.array_equal(ents3, ref_ents)
+    ref64 = orc.extrap_forward(sd, data, orc.get_time_offset_list(data, gran), gran, n_ent, n_rel, q[sel, 0], q[sel, 1], q[sel, 3], sh["n_layer"],
+                               "relu", dtype=torch.float64)[0].numpy()
+    U.assert_close_fp32(s3.cpu().numpy(), ref_s.numpy(), ref64, RTOL, ATOL_H, "extrapolation scores at the ICEWS14 shape")
+    assert torch.equal(s3, score[sel])                      # a query's scores do not depend on its batch
+    model.train()
+    score_t, _ = model(Q)
+    F.nll_loss(torch.log(F.softmax(score_t, dim=1) + 1e-12), torch.as_tensor(q[:, 2], dtype=torch.long).cuda()).backward()
+    grads = [p.grad for p in model.parameters() if p.grad is not None]
+    assert len(grads) >= 16 and all(torch.isfinite(g).all() for g in grads) and any(g.abs().max() > 0 for g in grads)
+
+
 def _grads(model):
     return {k: (v.grad.detach().cpu().numpy() if v.grad is not None else None) for k, v in model.named_parameters()}
 

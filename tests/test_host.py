@@ -114,7 +114,7 @@ def test_synthetic_generator_is_deterministic_and_shaped():
     assert len(np.unique(allt, axis=0)) == len(allt) and np.all(allt[:, 0] != allt[:, 2])
     indeg = np.bincount(allt[:, 2], minlength=2000)
     assert indeg.max() > 20 * indeg.mean()                      # hubs, as SURVEY.md §8(d) asks
-    assert set(SHAPES) == {"C2", "C3", "C4", "C5"}
+    assert set(SHAPES) == {"C2", "C3", "C4", "C5", "X"}          # X: C5's shape for the extrapolation setting
 
 
 def test_shard_helpers():
@@ -225,6 +225,61 @@ def test_query_sharding_world_size_2_gloo():
         ranks = fx["ranks"]
         np.testing.assert_allclose(ret["tot"], [(1.0 / ranks).sum(), (ranks <= 1).sum(), (ranks <= 10).sum(), len(ranks)])
         assert np.all(ret["gw"] == 3.0) and np.all(ret["gb"] == 30.0)
+
+
+def _gloo_train_worker(rank, world, port, ret):
+    import torch.distributed as dist
+    from red_gnn_amd.base_model import reference_loss
+    from red_gnn_amd.sharding import allreduce_gradients, entity_costs, split_batch
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        fx = U.load("tiny_fwd.npz")
+        g = U.oracle_graph(fx, "test")
+        p = {k: torch.tensor(np.asarray(v)).requires_grad_(v.dtype.kind == 'f') for k, v in U.params_of(fx).items()}
+        base = np.concatenate([fx["facts"], fx["train"]], 0)
+        subs, rels = fx["subs"], fx["rels"]
+        tails = torch.as_tensor(np.asarray([int(np.flatnonzero(l)[0]) for l in fx["labels"]]))
+        # the trainer's split of one batch (BaseModel.train_batch): cost-balanced, equal counts, loss scaled to the global batch
+        part = split_batch(entity_costs(base, int(fx["n_ent"]))[subs], world, rank)
+        sc = orc.forward(p, g, subs[part], rels[part], int(fx["cfg"][0]), act=str(fx["act"]))
+        loss = reference_loss(sc, tails[part]) * (len(subs) / len(part))
+        loss.backward()
+        params = [v for v in p.values()]
+        for v in params:
+            if v.grad is None:
+                v.grad = torch.zeros_like(v)
+        allreduce_gradients(params, dist)
+        parts = [None] * world
+        dist.all_gather_object(parts, part.tolist())
+        if rank == 0:
+            ret["grads"] = {k: v.grad.numpy().copy() for k, v in p.items()}
+            ret["parts"] = parts
+    finally:
+        dist.destroy_process_group()
+
+
+def test_trainer_cost_balanced_split_world_size_2_gloo():
+    """The trainer's N > 1 step (BaseModel.train_batch): every batch dealt over the ranks by estimated query cost, each rank's loss
+    scaled to the global batch (the reference's loss carries the factor n), gradients summed by one flat all-reduce - equal to the
+    single-process gradients of the whole batch (the oracle stands in for the HIP path on this CPU-only box)."""
+    import torch.multiprocessing as mp
+    from red_gnn_amd.base_model import reference_loss
+    port = 33500 + os.getpid() % 2000
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_gloo_train_worker, args=(2, port, ret), nprocs=2, join=True)
+        grads, parts = dict(ret["grads"]), list(ret["parts"])
+    fx = U.load("tiny_fwd.npz")
+    n = len(fx["subs"])
+    assert sorted(parts[0] + parts[1]) == list(range(n)) and abs(len(parts[0]) - len(parts[1])) <= 1
+    g = U.oracle_graph(fx, "test")
+    p = {k: torch.tensor(np.asarray(v)).requires_grad_(v.dtype.kind == 'f') for k, v in U.params_of(fx).items()}
+    tails = torch.as_tensor(np.asarray([int(np.flatnonzero(l)[0]) for l in fx["labels"]]))
+    reference_loss(orc.forward(p, g, fx["subs"], fx["rels"], int(fx["cfg"][0]), act=str(fx["act"])), tails).backward()
+    for k, v in p.items():
+        if v.grad is not None:
+            np.testing.assert_allclose(grads[k], v.grad.numpy(), rtol=2e-4, atol=2e-5, err_msg=k)
 
 
 def test_bench_byte_model():
