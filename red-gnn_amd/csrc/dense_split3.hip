@@ -208,6 +208,7 @@ __global__ __launch_bounds__(DENSE_T, 2) void dense_split3_kernel(DenseArgs A) {
     o_lo += (uint32_t)row0 * SR * 8u;
     typedef long lk __attribute__((ext_vector_type(KST)));
     const lk wl = *reinterpret_cast<const lk*>(wbase + (c_off + o_lo));
+
 #pragma unroll
     for (int s = 0; s < KST; ++s) {
       const h8 wh = o_hi < 65536u ? *reinterpret_cast<const h8*>(wbase + (a_off[s] + o_hi))

@@ -698,7 +698,8 @@ def test_temporal_extrapolation_vs_oracle(d, a, act, n_layer, B):
     class Q:
         src_idx, rel_idx, ts = q[:, 0], q[:, 1], q[:, 3]
 
-    score_all, (soft, ents) = model(Q)
+    with torch.no_grad():                      # (as main.py:376-384 evaluates; with gradients enabled the forward is differentiable)
+        score_all, (soft, ents) = model(Q)
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     otrace = []
     ref_s, ref_soft, ref_ents = orc.extrap_forward(sd, data, orc.get_time_offset_list(data, 24), 24, n_ent, n_rel, q[:, 0], q[:, 1], q[:, 3],
@@ -817,7 +818,8 @@ def test_temporal_extrapolation_icews14_shape():
     ref64 = orc.extrap_forward(sd, data, orc.get_time_offset_list(data, gran), gran, n_ent, n_rel, q[sel, 0], q[sel, 1], q[sel, 3], sh["n_layer"],
                                "relu", dtype=torch.float64)[0].numpy()
     U.assert_close_fp32(s3.cpu().numpy(), ref_s.numpy(), ref64, RTOL, ATOL_H, "extrapolation scores at the ICEWS14 shape")
-    assert torch.equal(s3, score[sel])                      # a query's scores do not depend on its batch
+    # a query's scores do not depend on its batch (up to the row-chunking of the dense GEMMs, which follows the row count)
+    np.testing.assert_allclose(s3.cpu().numpy(), score[sel].cpu().numpy(), rtol=1e-5, atol=1e-6)
     model.train()
     score_t, _ = model(Q)
     F.nll_loss(torch.log(F.softmax(score_t, dim=1) + 1e-12), torch.as_tensor(q[:, 2], dtype=torch.long).cuda()).backward()
