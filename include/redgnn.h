@@ -278,6 +278,15 @@ int rg_split3_product_check(int32_t which, int64_t n, int32_t d, const float* ag
                             const float* W_h, int32_t act, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
                             float* out, void* stream);
 
+/* ---- weight gradients of the dense training step: out[m, n] = G^T X (row-major) for G [n_rows, m] (row stride ldg), X [n_rows, n] (row
+ * stride ldx), n_rows in the millions, m <= 192, n <= 64 (wider products: call per column block) - autograd of models.py:41 (W_h),
+ * :83 (weight_ih / weight_hh of the GRU) and the hoisted :36 Ws_attn.  colsum [m] (may be NULL) = column sums of G (the bias
+ * gradients).  Exact fp32 products on v_mfma_f32_16x16x4_f32, rows read once, per-wave partial results added in a fixed order
+ * (bitwise reproducible).  scratch: rg_gram_tn_scratch_bytes(m, n) bytes. */
+size_t rg_gram_tn_scratch_bytes(int32_t m, int32_t n);
+int rg_gram_tn(const float* g, int64_t ldg, int32_t m, const float* x, int64_t ldx, int32_t n, int64_t n_rows, float* out, float* colsum,
+               void* scratch_dev, size_t scratch_bytes, void* stream);
+
 /* ---- filtered ranking: replaces utils.py:7-14 cal_ranks (+ the filter loop base_model.py:107-115)
  * scores device fp32 [B, n_ent]; answers / filters as CSR over queries (device int32):
  * ans_ptr [B+1], ans_idx [ans_ptr[B]], filt_ptr [B+1], filt_idx [..].  ranks_out device fp32

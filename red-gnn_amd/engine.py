@@ -485,6 +485,42 @@ def xlayer_bwd(frontier, graph, level, n_old, q_time, loop_time, row_time, n_dat
     return g_hp, g_rp, g_tp, g_as, g_ar, g_aq, g_w
 
 
+_GRAM_SCRATCH = {}
+
+
+def gram_tn(g, x, colsum=False):
+    """g^T x for node-row matrices g [N, m], x [N, n] (unit-stride columns; rows may be spaced: column blocks of wider buffers work
+    without a copy), N in the millions: rg_gram_tn (exact fp32 MFMA products, rows read once, deterministic).  Returns out [m, n], or
+    (out, column sums of g [m]) with colsum=True.  Products wider than 192 x 64 are tiled over column blocks."""
+    assert g.is_cuda and x.is_cuda and g.dtype == torch.float32 and x.dtype == torch.float32 and g.shape[0] == x.shape[0]
+    assert g.stride(1) == 1 and x.stride(1) == 1
+    n_rows, m, n = g.shape[0], g.shape[1], x.shape[1]
+    L = _lib.lib()
+    out = torch.empty((m, n), dtype=torch.float32, device=g.device)
+    cs = torch.empty(m, dtype=torch.float32, device=g.device) if colsum else None
+    for m0 in range(0, m, 192):
+        mc = min(192, m - m0)
+        for n0 in range(0, n, 64):
+            nc = min(64, n - n0)
+            nbytes = L.rg_gram_tn_scratch_bytes(mc, nc)
+            key = (str(g.device), torch.cuda.current_stream(g.device).cuda_stream)
+            scratch = _GRAM_SCRATCH.get(key)
+            if scratch is None or scratch.numel() < nbytes:
+                scratch = _GRAM_SCRATCH[key] = torch.empty(nbytes, dtype=torch.uint8, device=g.device)
+            tile = out if (mc == m and nc == n) else torch.empty((mc, nc), dtype=torch.float32, device=g.device)
+            cs_t = None
+            if colsum and n0 == 0:
+                cs_t = cs if mc == m else torch.empty(mc, dtype=torch.float32, device=g.device)
+            gv, xv = g[:, m0:m0 + mc], x[:, n0:n0 + nc]
+            _lib.check(L.rg_gram_tn(C.c_void_p(gv.data_ptr()), g.stride(0), mc, C.c_void_p(xv.data_ptr()), x.stride(0), nc, n_rows,
+                                    _lib.ptr(tile), _lib.ptr(cs_t), _lib.ptr(scratch), scratch.numel(), _lib.stream_ptr()))
+            if tile is not out:
+                out[m0:m0 + mc, n0:n0 + nc] = tile
+            if cs_t is not None and cs_t is not cs:
+                cs[m0:m0 + mc] = cs_t
+    return (out, cs) if colsum else out
+
+
 _BLAS_CHOICE = [None]
 
 

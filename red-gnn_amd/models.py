@@ -64,6 +64,8 @@ def _gram_tn(g, x):
     n_rows = g.shape[0]
     if n_rows < _TALL_ROWS:
         return g.t() @ x
+    if g.is_cuda and g.dtype == torch.float32 and x.dtype == torch.float32:
+        return engine.gram_tn(g, x)           # one HIP kernel: rows read once, exact fp32 MFMA products, deterministic sums
     c = n_rows // _TALL_CHUNKS
     body = _TALL_CHUNKS * c
     out = torch.bmm(_row_chunks(g, _TALL_CHUNKS, c).transpose(1, 2), _row_chunks(x, _TALL_CHUNKS, c)).sum(0)
@@ -152,8 +154,13 @@ class _DenseStep(torch.autograd.Function):
         if engine.dense_train_bwd_supported(d) and n >= _FUSED_BWD_ROWS:
             # one fused kernel for everything per node row (rg_dense_train_bwd); the weight gradients below are sums over rows
             dgi, dgh, dpre, g_agg, dh0 = engine.dense_train_bwd(g_h, ws, x, mask if has_mask else None, ctx.keep, ctx.act, W_h, w_ih, w_hh)
-            dbi, dbh = dgi.sum(0), dgh.sum(0)
             h0 = ws.view(n, 5, d)[:, 3]                          # a column block of the workspace: no copy
+            if n >= _TALL_ROWS:                                  # weight and bias gradients in one pass over the rows each (rg_gram_tn)
+                (g_wih, dbi), (g_whh, dbh) = engine.gram_tn(dgi, x, colsum=True), engine.gram_tn(dgh, h0, colsum=True)
+                g_wh = engine.gram_tn(dpre, agg)
+                g_prev = dh0[old_new.long()] if ctx.n_old else dh0.new_zeros((0, d))
+                return g_agg, g_prev, g_wh, g_wih, g_whh, dbi, dbh, None, None, None, None, None, None
+            dbi, dbh = dgi.sum(0), dgh.sum(0)
         else:
             dgi, dgh, dh0, dbi, dbh = torch.ops.aten._thnn_fused_gru_cell_backward(g_h.contiguous(), ws, True)
             h0 = ws.view(n, 5, d)[:, 3]

@@ -1337,6 +1337,28 @@ def test_split_dense_kernel_fits_its_weight_scale(scale, d):
             assert float((a_s[:, :a].double() - as_ref).abs().max()) < 2e-6 * max(scale, float(as_ref.abs().max())), (prec, scale)
 
 
+@pytest.mark.parametrize("n_rows,m,n", [(200_000, 192, 64), (70_001, 144, 48), (33_000, 64, 64), (40_000, 8, 64), (5, 192, 64), (100_003, 384, 128), (50_000, 60, 20)])
+def test_gram_tn_weight_gradient_kernel(n_rows, m, n):
+    """rg_gram_tn: out = G^T X and the column sums of G over node rows (the weight / bias gradients of the dense training step) against
+    fp64, for every width the presets use (d = 64: 192 x 64; d = 48: 144 x 48; the attention projection: 8 x 64; d = 128 tiled over
+    column blocks; widths that are no multiple of 16), on strided column blocks of wider buffers, ragged row counts, and twice: the
+    sums are bitwise reproducible."""
+    from red_gnn_amd import engine
+    torch.manual_seed(n_rows % 97)
+    dev = "cuda"
+    gbuf = torch.randn(n_rows, m + 24, device=dev)
+    xbuf = torch.randn(n_rows, n + 8, device=dev)
+    g, x = gbuf[:, 8:8 + m], xbuf[:, 4:4 + n]            # column blocks: rows are spaced, columns unit-stride
+    out, cs = engine.gram_tn(g, x, colsum=True)
+    ref = g.double().t() @ x.double()
+    scale = float(ref.abs().max())
+    assert float((out.double() - ref).abs().max()) <= 2e-6 * max(scale, (n_rows ** 0.5))
+    assert float((cs.double() - g.double().sum(0)).abs().max()) <= 2e-6 * max(float(g.double().sum(0).abs().max()), n_rows ** 0.5)
+    out2, cs2 = engine.gram_tn(g, x, colsum=True)
+    assert torch.equal(out, out2) and torch.equal(cs, cs2)
+    assert torch.equal(engine.gram_tn(g, x), out)         # the product does not depend on the column-sum option
+
+
 def _split3_roundtrip(x, parts=False):
     import ctypes
     from red_gnn_amd import _lib
