@@ -66,9 +66,9 @@ def dense_kernel_of(d, precision):
     """(kernel name, arithmetic) rg_dense_fwd runs for this width and precision (csrc/dense.hip dispatch)."""
     if precision == "f16x2":
         return ("dense_split_kernel" if d <= 64 else "dense128_split_kernel"), "f16x2"
-    if precision == "f16x3" and d <= 64:
-        return "dense_split3_kernel", "f16x3"
-    return ("dense_kernel" if d <= 64 else "dense128_kernel"), "f32"       # f32, and f16x3 at d = 128
+    if precision == "f16x3":
+        return ("dense_split3_kernel" if d <= 64 else "dense128_split3_kernel"), "f16x3"
+    return ("dense_kernel" if d <= 64 else "dense128_kernel"), "f32"
 
 
 def dense_roofline(dense_ms, d, attn_dim, n_layer, batch, precision):

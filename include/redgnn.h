@@ -253,7 +253,7 @@ int rg_dense_fwd(int64_t n, int32_t d, int32_t ld, const float* agg, const float
                  const float* W_final, const int32_t* nodes, int32_t n_ent, float* scores_all,
                  float* hidden_out, int32_t precision, void* scratch, int64_t scratch_bytes, void* stream);
 /* scratch: device memory of rg_dense_scratch_bytes(d, precision) bytes, 256-B aligned (0 bytes / NULL for every case but d = 128 with
- * precision 1, whose weights stream through LDS from a split image written there first).  Contents are dead after the call. */
+ * precision 1 or 2, whose weights stream through LDS from a split image written there first).  Contents are dead after the call. */
 int64_t rg_dense_scratch_bytes(int32_t d, int32_t precision);
 /* precision: how the matrix products are evaluated.
  *   0  v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulation (what the reference's fp32 GEMMs compute up to sum order)
@@ -262,8 +262,7 @@ int64_t rg_dense_scratch_bytes(int32_t d, int32_t precision);
  *      of 1e-7, at 3/16 of the matrix-pipe time
  *   2  every fp32 operand as an EXACT three-term f16 split (hi + mid + lo = all 24 bits; csrc/split3.h), the six partial products of
  *      order >= 2^-22 per product on v_mfma_f32_16x16x32_f16 / _bf8_bf8 with fp32 accumulation: fp32 arithmetic (operands exact,
- *      products good to 2^-31, fp32 sums) at 6/16 of the matrix-pipe time of precision 0.  d <= 64; at d = 128 it runs precision 0's
- *      kernel.  The model's default. */
+ *      products good to 2^-31, fp32 sums) at 6/16 of the matrix-pipe time of precision 0.  The model's default. */
 
 /* Test hook of precision 2's operand form: splits each of the n_rows rows of `cols` floats on the device exactly as the dense kernels
  * do (row scale = the power of two that takes the row's largest magnitude to [2^14, 2^15)) and writes back[n_rows, cols] =

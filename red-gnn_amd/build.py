@@ -19,7 +19,7 @@ FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
 
 
 # the files with the most template instances first, so that the longest compile starts at once
-_SLOW_FIRST = ["layer_bwd.hip", "tlayer_bwd.hip", "layer_fwd.hip", "tlayer_fwd.hip", "dense.hip", "dense128.hip", "dense_bwd.hip"]
+_SLOW_FIRST = ["layer_bwd.hip", "tlayer_bwd.hip", "layer_fwd.hip", "tlayer_fwd.hip", "dense.hip", "dense128.hip", "dense_bwd.hip", "dense128_split3.hip", "dense_split3.hip"]
 
 
 def _sources():

@@ -331,7 +331,8 @@ int launch(const DenseArgs& A, hipStream_t s) {
 }  // namespace
 
 extern "C" int64_t rg_dense_scratch_bytes(int32_t d, int32_t precision) {
-  return d == 128 && precision == 1 ? rg::dense128_split_scratch_bytes() : 0;
+  if (d != 128) return 0;
+  return precision == 1 ? rg::dense128_split_scratch_bytes() : precision == 2 ? rg::dense128_split3_scratch_bytes() : 0;
 }
 
 extern "C" int rg_dense_fwd_supported(int32_t d, int32_t attn_dim) { return ((d >= 1 && d <= 64) || d == 128) && attn_dim <= 16; }
@@ -363,9 +364,9 @@ static int dense_fwd_impl(int64_t n, const int32_t* n_dev, int64_t n_hint, int32
   A.hidden_out = (float4*)hidden_out; A.act = act;
   A.n_tiles = (int)rg::ceil_div(n, 16);
   hipStream_t s = (hipStream_t)stream;
-  // (d = 128: the exact three-term kernel is not built for streamed weights; precision 2 takes the f32 MFMA kernel there - the same
-  // fp32 arithmetic, slower)
-  if (d == 128) return precision == 1 ? rg::dense128_split_launch(A, scratch, scratch_bytes, s) : rg::dense128_launch(A, s);
+  if (d == 128)
+    return precision == 1 ? rg::dense128_split_launch(A, scratch, scratch_bytes, s)
+         : precision == 2 ? rg::dense128_split3_launch(A, scratch, scratch_bytes, s) : rg::dense128_launch(A, s);
   if (precision == 1) return rg::dense_split_launch(A, s);
   if (precision == 2) return rg::dense_split3_launch(A, s);
   return d <= 32 ? launch<2, false>(A, s) : launch<4, false>(A, s);

@@ -51,6 +51,9 @@ int dense128_launch(const DenseArgs& A, hipStream_t s);
 int dense_split_launch(const DenseArgs& A, hipStream_t s);
 // d <= 64 with the products as exact three-term f16 splits = fp32 arithmetic on the f16 pipe (dense_split3.hip)
 int dense_split3_launch(const DenseArgs& A, hipStream_t s);
+// d = 128 with exact three-term splits, weights streamed from a split image in a caller-provided scratch (dense128_split3.hip)
+int64_t dense128_split3_scratch_bytes();
+int dense128_split3_launch(const DenseArgs& A, void* scratch, int64_t scratch_bytes, hipStream_t s);
 // d = 128 with split products: the weights' split image goes through a caller-provided scratch (dense128_split.hip)
 int64_t dense128_split_scratch_bytes();
 int dense128_split_launch(const DenseArgs& A, void* scratch, int64_t scratch_bytes, hipStream_t s);

@@ -170,18 +170,22 @@ __global__ __launch_bounds__(DENSE_T, 2) void dense_split3_kernel(DenseArgs A) {
     return m;
   };
   // B fragments of f * sc
+  // (the bf8 form is taken from the SAME scaled values: the 2^-8 that pairs it with the weights' lo image, stored times 2^8, is applied
+  // where the bf8 chain joins the f16 chain - one fma per accumulator element instead of a multiplication per operand element)
   auto split_frag = [&](const float (&f)[KS], float sc, Frag<KST>& F) {
-    const float sc8 = sc * LO8_INV;
 #pragma unroll
     for (int s = 0; s < KST; ++s) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = f[8 * s + j] * sc;
       h4 h0, m0, l0, h1, m1, l1;
-      split3_4(f[8 * s + 0] * sc, f[8 * s + 1] * sc, f[8 * s + 2] * sc, f[8 * s + 3] * sc, h0, m0, l0);
-      split3_4(f[8 * s + 4] * sc, f[8 * s + 5] * sc, f[8 * s + 6] * sc, f[8 * s + 7] * sc, h1, m1, l1);
+      split3_4(v[0], v[1], v[2], v[3], h0, m0, l0);
+      split3_4(v[4], v[5], v[6], v[7], h1, m1, l1);
       F.h[s] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
       F.m[s] = __builtin_shufflevector(m0, m1, 0, 1, 2, 3, 4, 5, 6, 7);
       F.l[s] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
-      const uint32_t q0 = to_bf8x4(f[8 * s + 0] * sc8, f[8 * s + 1] * sc8, f[8 * s + 2] * sc8, f[8 * s + 3] * sc8);
-      const uint32_t q1 = to_bf8x4(f[8 * s + 4] * sc8, f[8 * s + 5] * sc8, f[8 * s + 6] * sc8, f[8 * s + 7] * sc8);
+      const uint32_t q0 = to_bf8x4(v[0], v[1], v[2], v[3]);
+      const uint32_t q1 = to_bf8x4(v[4], v[5], v[6], v[7]);
       F.q[s] = (long)(((uint64_t)q1 << 32) | q0);
     }
   };
@@ -201,8 +205,9 @@ __global__ __launch_bounds__(DENSE_T, 2) void dense_split3_kernel(DenseArgs A) {
   // The bf8 products keep an accumulator chain of their own that a vector add joins to the f16 chain: with both MFMA forms chained
   // through ONE accumulator (hipcc 7.2, gfx950) the sums came out wrong by tens of percent - with or without eight wait states on
   // either side of the bf8 instruction, and right again as soon as a branch separated the instructions (tools/r3_variants.sh).
-  auto mma = [&](uint32_t o_hi, uint32_t o_mid, uint32_t o_lo, int row0, const Frag<KST>& F, f32x4& acc) {
-    f32x4 acc8 = {0.f, 0.f, 0.f, 0.f};
+  // (acc8: the bf8 chain of the accumulator; products that add up in one accumulator - W_ih x and W_hh h of a gate - share it, and
+  // `join` brings it in once)
+  auto mma = [&](uint32_t o_hi, uint32_t o_mid, uint32_t o_lo, int row0, const Frag<KST>& F, f32x4& acc, f32x4& acc8) {
     o_hi += (uint32_t)row0 * SR * 16u;
     o_mid += (uint32_t)row0 * SR * 16u;
     o_lo += (uint32_t)row0 * SR * 8u;
@@ -222,7 +227,10 @@ __global__ __launch_bounds__(DENSE_T, 2) void dense_split3_kernel(DenseArgs A) {
       acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, F.m[s], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, F.h[s], acc, 0, 0, 0);
     }
-    acc += acc8;
+  };
+  auto join = [&](f32x4& acc, const f32x4& acc8) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = fmaf(acc8[r], LO8_INV, acc[r]);
   };
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
@@ -298,8 +306,9 @@ __global__ __launch_bounds__(DENSE_T, 2) void dense_split3_kernel(DenseArgs A) {
       const float sc_out = inv1 * inv_w * (ACT == 2 ? -2.0f * LOG2E : 1.0f);
 #pragma unroll
       for (int ob = 0; ob < NB; ++ob) {
-        f32x4 acc = zero4;
-        mma(O_WH, O_WH + P_W, L_WH, 16 * ob, F, acc);
+        f32x4 acc = zero4, acc8 = zero4;
+        mma(O_WH, O_WH + P_W, L_WH, 16 * ob, F, acc, acc8);
+        join(acc, acc8);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float v = acc[r] * sc_out;
@@ -346,12 +355,28 @@ __global__ __launch_bounds__(DENSE_T, 2) void dense_split3_kernel(DenseArgs A) {
 #pragma unroll
       for (int ob = 0; ob < NB; ++ob) {
         f32x4 ar = zero4, az = zero4, ai = zero4, ag = zero4;
-        mma(O_WIH, O_WIH + P_G, L_WIH, 0 * DP + 16 * ob, F, ar);
-        if constexpr (OLD) mma(O_WHH, O_WHH + P_G, L_WHH, 0 * DP + 16 * ob, H, ar);
-        mma(O_WIH, O_WIH + P_G, L_WIH, 1 * DP + 16 * ob, F, az);
-        if constexpr (OLD) mma(O_WHH, O_WHH + P_G, L_WHH, 1 * DP + 16 * ob, H, az);
-        mma(O_WIH, O_WIH + P_G, L_WIH, 2 * DP + 16 * ob, F, ai);
-        if constexpr (OLD) mma(O_WHH, O_WHH + P_G, L_WHH, 2 * DP + 16 * ob, H, ag);
+        {
+          f32x4 r8 = zero4;
+          mma(O_WIH, O_WIH + P_G, L_WIH, 0 * DP + 16 * ob, F, ar, r8);
+          if constexpr (OLD) mma(O_WHH, O_WHH + P_G, L_WHH, 0 * DP + 16 * ob, H, ar, r8);
+          join(ar, r8);
+        }
+        {
+          f32x4 z8 = zero4;
+          mma(O_WIH, O_WIH + P_G, L_WIH, 1 * DP + 16 * ob, F, az, z8);
+          if constexpr (OLD) mma(O_WHH, O_WHH + P_G, L_WHH, 1 * DP + 16 * ob, H, az, z8);
+          join(az, z8);
+        }
+        {
+          f32x4 i8 = zero4;
+          mma(O_WIH, O_WIH + P_G, L_WIH, 2 * DP + 16 * ob, F, ai, i8);
+          join(ai, i8);
+        }
+        if constexpr (OLD) {
+          f32x4 g8 = zero4;
+          mma(O_WHH, O_WHH + P_G, L_WHH, 2 * DP + 16 * ob, H, ag, g8);
+          join(ag, g8);
+        }
         const float4 br = *reinterpret_cast<const float4*>(bias_l + 0 * DP + 16 * ob + 4 * hq);
         const float4 bz = *reinterpret_cast<const float4*>(bias_l + 1 * DP + 16 * ob + 4 * hq);
         const float4 bi = *reinterpret_cast<const float4*>(bias_l + 2 * DP + 16 * ob + 4 * hq);
@@ -398,15 +423,17 @@ __global__ __launch_bounds__(DENSE_T, 2) void dense_split3_kernel(DenseArgs A) {
     constexpr float inv_n = 1.0f / 16384.0f;
     if (A.Ws || A.W_final) split_frag(hn, 16384.0f, F);
     if (A.Ws) {       // rows e = 4*hq + r of block 0
-      f32x4 acc = zero4;
-      mma(O_E, O_E + P_E, L_E, 0, F, acc);
+      f32x4 acc = zero4, acc8 = zero4;
+      mma(O_E, O_E + P_E, L_E, 0, F, acc, acc8);
+      join(acc, acc8);
       const float sc_e = inv_we * inv_n;
       if (node_ok && 4 * hq < A.ap)
         reinterpret_cast<float4*>(A.a_s_out + node * A.ap)[hq] = make_float4(acc[0] * sc_e, acc[1] * sc_e, acc[2] * sc_e, acc[3] * sc_e);
     }
     if (A.W_final) {  // row 16 = register 0 of quarter 0 of block 1
-      f32x4 acc = zero4;
-      mma(O_E, O_E + P_E, L_E, 16, F, acc);
+      f32x4 acc = zero4, acc8 = zero4;
+      mma(O_E, O_E + P_E, L_E, 16, F, acc, acc8);
+      join(acc, acc8);
       if (node_ok && hq == 0) A.scores[(int64_t)qe.x * A.n_ent + qe.y] = acc[0] * (inv_we * inv_n);
     }
   }

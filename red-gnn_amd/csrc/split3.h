@@ -12,8 +12,9 @@
 //     W_hi X_hi + W_hi X_mid + W_mid X_hi + W_hi X_lo + W_mid X_mid + W_lo X_hi      (dropped: <= 3 * 2^-33 |W X|)
 // accumulated in the MFMA's fp32 accumulator: operands exact, products good to 2^-31, sums in fp32 - fp32 arithmetic on the f16 pipe
 // at 6/16 of the f32 forms' time.  The weights' lo part (one significant bit) is stored as bf8 (e5m2) scaled by 2^8 - the same
-// exponent range as f16 subnormals reach - and multiplied on the bf8 form of the same MFMA with X_hi rounded to bf8 (3 significant
-// bits: an error below 2^-3 of a 2^-22 term), which keeps the d = 64 weight images inside the CU's 160 KB of LDS.
+// exponent range as f16 subnormals reach - and multiplied on the bf8 form of the same MFMA with X rounded to bf8 (3 significant
+// bits: an error below 2^-3 of a 2^-22 term; the 2^-8 comes back where that chain's sums join the others), which keeps the d = 64
+// weight images inside the CU's 160 KB of LDS.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -26,7 +27,7 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef float f2v __attribute__((ext_vector_type(2)));
 
-constexpr float LO8_SCALE = 256.0f;            // weights' lo part is stored as bf8(lo * 2^8), X_hi enters that product as bf8(X / 2^8)
+constexpr float LO8_SCALE = 256.0f;            // weights' lo part is stored as bf8(lo * 2^8); the bf8 products' sums are scaled back by 2^-8
 constexpr float LO8_INV = 1.0f / 256.0f;
 
 // x - float(hi.lo / hi.hi) in one v_fma_mix_f32 (exact: see above)
@@ -96,7 +97,7 @@ __device__ __forceinline__ void split3_4_lo8(float a, float b, float c, float d,
   mid = __builtin_shufflevector(m0, m1, 0, 1, 2, 3);
   lo8 = (uint32_t)w;
 }
-// four floats (scaled by the operand's scale / 2^8) -> four bf8 bytes (the activations' partner of the weights' lo8 image)
+// four scaled floats (below 2^15) -> four bf8 bytes (the activations' partner of the weights' lo8 image)
 __device__ __forceinline__ uint32_t to_bf8x4(float a, float b, float c, float d) {
   int w = 0;
   w = __builtin_amdgcn_cvt_pk_bf8_f32(a, b, w, false);

@@ -360,8 +360,7 @@ def test_bench_dense_roofline_per_precision():
     s3 = bench.dense_roofline([(0.3, rows[0]), (2.4, rows[1]), (2.9, rows[2])] * 2, 64, 5, 3, 1024, "f16x3")
     assert s3["bound"] == "mfma" and s3["kernel"] == "dense_split3_kernel" and s3["peak"] == 2500.0 and 0.0 < s3["frac"] < 1.0
     assert abs(s3["achieved"] - 6 * s3["useful_tflops"]) < 1e-9 and 0.0 < s3["hbm_algorithmic_frac"] < 1.0
-    # at d = 128 the default precision runs the f32 MFMA kernel
-    assert bench.dense_kernel_of(128, "f16x3") == ("dense128_kernel", "f32") and bench.dense_kernel_of(48, "f16x3")[0] == "dense_split3_kernel"
+    assert bench.dense_kernel_of(128, "f16x3") == ("dense128_split3_kernel", "f16x3") and bench.dense_kernel_of(48, "f16x3")[0] == "dense_split3_kernel"
     assert bench.DTYPE_OF["f16x3"] == "f32" and bench.DTYPE_OF["f16x2"] != "f32"
 
 
