@@ -1,5 +1,5 @@
 """Build the profiles/traffic_layer_fwd.json entry of one workload from the PMC summary that tools/pmc_traffic.sh leaves
-(gpurun_out/r2_traffic_<config>_<batch>/summary.json): HBM bytes of the last step's rg_layer_fwd launches (and of its dense launches).
+(gpurun_out/r3_traffic_<config>_<batch>/summary.json): HBM bytes of the last step's rg_layer_fwd launches (and of its dense launches).
     python tools/traffic_entry.py <summary.json> <config> <batch> <rg_version> <n_layer> <committed summary path> [steps_layer steps_dense]
 steps_*: how many eval steps the profiled command ran with the layer kernels / with each dense kernel (default 3 = --steps 2 --warmup 1;
 a bench run that also times the exact-fp32 dense step afterwards runs the layer kernels for 3 more steps).
@@ -11,7 +11,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LAYER_KERNELS = ("layer_fwd_wp_kernel", "layer_fwd_kernel", "combine_kernel")
-DENSE_KERNELS = ("dense_split_kernel", "dense_kernel", "dense128")
+DENSE_KERNELS = ("dense_split3_kernel", "dense_split_kernel", "dense_kernel", "dense128")
 
 
 def last_step(vals, per_step):
