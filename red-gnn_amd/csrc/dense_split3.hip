@@ -12,6 +12,7 @@
 //     rows of the NEXT tile are requested as soon as this tile's are split - a full tile of work ahead of their use.
 // rg_dense_fwd(..., precision = 2).  precision 0 = v_mfma_f32_16x16x4_f32 (dense.hip), 1 = two-term splits (dense_split.hip).
 #include <type_traits>
+#include <utility>
 #include "dense_common.h"
 #include "split3.h"
 
@@ -46,13 +47,25 @@ struct Geo {
   }
 };
 
+// an empty volatile asm that consumes and redefines a register: volatile asms keep their order, so the instruction that produced the value
+// stays ahead of it and its users stay behind it - the pipelined gate loop fixes its instruction order with these
+#define RG_PIN(x) asm volatile("" : "+v"(x))
+
+template <class Fn, int... I>
+__device__ __forceinline__ void static_for_impl(Fn&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class Fn>
+__device__ __forceinline__ void static_for(Fn&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
 template <int KST>
 struct Frag {          // B operand of one node row: hi / mid / lo f16 and the bf8 form of x / 2^8, per k-step
   h8 h[KST], m[KST], l[KST];
   long q[KST];
 };
 
-template <int NB, int ACT>
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// PROBE: the test-hook build (rg_split3_product_check): writes one of the products instead of the new state
+template <int NB, int ACT, bool PROBE>
 __global__ __launch_bounds__(DENSE_T, 2) void dense_split3_kernel(DenseArgs A) {
   constexpr int DP = 16 * NB;
   using G = Geo<DP>;
@@ -69,6 +82,7 @@ __global__ __launch_bounds__(DENSE_T, 2) void dense_split3_kernel(DenseArgs A) {
   constexpr uint32_t O_LO_END = O_F16_END + L_E + 32 * SR * 8;
   extern __shared__ float4 lds[];
   if (A.n_dev) { A.n = *A.n_dev; A.n_tiles = (int)((A.n + 15) / 16); }
+  if (A.n_tiles <= 0) return;
   char* const lds_b = reinterpret_cast<char*>(lds);
   float* bias_l = reinterpret_cast<float*>(lds_b + O_LO_END);                     // [4][DP], pre-multiplied by the exp2 factors of their gates
   uint32_t* wmax_bits = reinterpret_cast<uint32_t*>(bias_l + 4 * DP);
@@ -241,39 +255,49 @@ __global__ __launch_bounds__(DENSE_T, 2) void dense_split3_kernel(DenseArgs A) {
   uint32_t col_ok = 0;                                  // bit ob: the lane's chunk of block ob lies inside the row
 #pragma unroll
   for (int ob = 0; ob < NB; ++ob) col_ok |= (4 * ob + hq < A.ld4 ? 1u : 0u) << ob;
-  auto load_prev = [&](int t) -> int {
+  // Every load of the tile loop is unconditional, from an address clamped into its buffer (rows beyond n read row n - 1, tiles beyond the
+  // last read the last, column chunks beyond the row read chunk 0): rows that do not exist are never stored, chunk 0 again leaves the
+  // row's maximum where it was and meets zero weight columns, and a node without an old state gets a zero row scale.  No load sits
+  // behind a lane mask, so the loop body stays a handful of basic blocks and its memory waits stay counted ones.
+  const int64_t n_last = A.n - 1;
+  auto tile_row = [&](int t) -> int64_t {              // the lane's (clamped) row of tile t
+    int ts = __builtin_amdgcn_readfirstlane(t);
+    ts = ts < A.n_tiles ? ts : A.n_tiles - 1;
+    const int64_t r = (int64_t)ts * 16 + li;
+    return r < n_last ? r : n_last;
+  };
+  uint32_t col_off[NB];                                // float4 offset of the lane's chunk of block ob inside a row (clamped)
+#pragma unroll
+  for (int ob = 0; ob < NB; ++ob) col_off[ob] = ((col_ok >> ob) & 1u) ? (uint32_t)(4 * ob + hq) : (uint32_t)(hq < A.ld4 ? hq : 0);
+  // (the index as loaded: `prev_of` masks it with the row's existence where it is USED, a tile later - a select next to the load would
+  // wait for it on the spot, and with it for every older load and store of the wave)
+  auto load_prev = [&](int t) -> int { return A.prev_idx ? A.prev_idx[tile_row(t)] : -1; };
+  auto prev_of = [&](int t, int raw) -> int {
     const int ts = __builtin_amdgcn_readfirstlane(t);
-    int p = -1;
-    if (A.prev_idx && ts < A.n_tiles && (int64_t)ts * 16 + li < A.n) p = (A.prev_idx + (int64_t)ts * 16)[li];
-    return p;
+    return (ts < A.n_tiles && (int64_t)ts * 16 + li < A.n) ? raw : -1;
   };
   auto load_agg = [&](int t, float4 (&va)[NB]) {
-    const int ts = __builtin_amdgcn_readfirstlane(t);
-    const bool row_ok = ts < A.n_tiles && (int64_t)ts * 16 + li < A.n;
-    const float4* arow = A.agg + (int64_t)ts * 16 * A.ld4;                  // scalar
+    const float4* arow = A.agg + tile_row(t) * A.ld4;
 #pragma unroll
-    for (int ob = 0; ob < NB; ++ob) {
-      va[ob] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row_ok && ((col_ok >> ob) & 1u)) va[ob] = arow[lane_off + 4 * ob];
-    }
+    for (int ob = 0; ob < NB; ++ob) va[ob] = arow[col_off[ob]];
   };
-  auto load_old = [&](int p, float4 (&vh)[NB]) {       // p < 0: a new node (or no row): h = 0
-    const float4* hrow = A.hprev + ((int64_t)(p < 0 ? 0 : p) * A.ld4 + hq);
+  // p < 0 (a new node, or no row): the lane reads its agg row once more (some address it may read: the old-state buffer may be empty)
+  // and the row gets a zero scale
+  auto load_old = [&](int t, int p, float4 (&vh)[NB]) {
+    if (!A.prev_idx) return;
+    const float4* hrow = p < 0 ? A.agg + tile_row(t) * A.ld4 : A.hprev + (int64_t)p * A.ld4;
 #pragma unroll
-    for (int ob = 0; ob < NB; ++ob) {
-      vh[ob] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (p >= 0 && ((col_ok >> ob) & 1u)) vh[ob] = hrow[4 * ob];
-    }
+    for (int ob = 0; ob < NB; ++ob) vh[ob] = hrow[col_off[ob]];
   };
 
   if (wv >= NW / 2) __builtin_amdgcn_s_sleep(64);     // de-phase the two waves of a SIMD (see dense.hip)
   float4 va[NB], vh[NB];
   const int t_step = gridDim.x * NW;
   int t = blockIdx.x * NW + wv;
-  int p_cur = load_prev(t);
+  int p_cur = prev_of(t, load_prev(t));
   load_agg(t, va);
-  int p_next = load_prev(t + t_step);
-  load_old(p_cur, vh);
+  int p_next = load_prev(t + t_step);      // raw
+  load_old(t, p_cur, vh);
   for (; t < A.n_tiles; t += t_step) {
     const int ts = __builtin_amdgcn_readfirstlane(t);
     const int64_t row0 = (int64_t)ts * 16;
@@ -298,7 +322,7 @@ __global__ __launch_bounds__(DENSE_T, 2) void dense_split3_kernel(DenseArgs A) {
     // (the readout's (query, entity) pair too: fetched at the end it would make the wave wait out its own prefetch)
     const int64_t node = row0 + li;
     int2 qe = make_int2(0, 0);
-    if (A.W_final && node_ok && hq == 0) qe = reinterpret_cast<const int2*>(A.nodes)[node];
+    if (A.W_final) qe = reinterpret_cast<const int2*>(A.nodes)[node < n_last ? node : n_last];
 
     // ---- stage 1: x = act(W_h agg) ------------------------------------------------------------------------------------------
     float xf[KS];
@@ -319,13 +343,16 @@ __global__ __launch_bounds__(DENSE_T, 2) void dense_split3_kernel(DenseArgs A) {
       }
     }
 
-    if (A.probe == 1) {      // test hook: the stage-1 product itself
+    // (taken here, ahead of this tile's stores: a wait for the pair after them would wait for them as well)
+    const int64_t score_at = (int64_t)qe.x * A.n_ent + qe.y;
+
+    if (PROBE && A.probe == 1) {      // test hook: the stage-1 product itself
 #pragma unroll
       for (int ob = 0; ob < NB; ++ob)
         if (node_ok && ((col_ok >> ob) & 1u))
           (A.hidden_out + row0 * A.ld4)[lane_off + 4 * ob] = make_float4(xf[4 * ob], xf[4 * ob + 1], xf[4 * ob + 2], xf[4 * ob + 3]);
-      p_cur = p_next;
-      load_old(p_cur, vh);
+      p_cur = prev_of(t + t_step, p_next);
+      load_old(t + t_step, p_cur, vh);
       p_next = load_prev(t + 2 * t_step);
       continue;
     }
@@ -333,6 +360,11 @@ __global__ __launch_bounds__(DENSE_T, 2) void dense_split3_kernel(DenseArgs A) {
     // ---- GRU gates: x and the old state share one row scale, so that W_ih x and W_hh h add inside the accumulators; the new state
     // goes out in fragment layout as its blocks complete, and into the projection fragments ------------------------------------------
     float hn[KS];
+    // new-state rows go out through a buffer descriptor of this tile's valid rows: lanes beyond them (and columns beyond the row) are
+    // dropped by its range check instead of by a branch, so that the whole gate loop is ONE scheduling region
+    const int rows_valid = (int)(A.n - row0 < 16 ? (A.n - row0 > 0 ? A.n - row0 : 0) : 16);
+    const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<char*>(A.hidden_out + row0 * A.ld4), 0, rows_valid * A.ld4 * 16, 0x00020000);
     auto gru = [&](auto has_old) {
       constexpr bool OLD = decltype(has_old)::value;
       Frag<KST> H;
@@ -341,20 +373,26 @@ __global__ __launch_bounds__(DENSE_T, 2) void dense_split3_kernel(DenseArgs A) {
         float hf[KS];
 #pragma unroll
         for (int ob = 0; ob < NB; ++ob) { hf[4 * ob] = vh[ob].x; hf[4 * ob + 1] = vh[ob].y; hf[4 * ob + 2] = vh[ob].z; hf[4 * ob + 3] = vh[ob].w; }
-        row_scale(row_max(hf, row_max(xf, 0.f)), sc, inv);
-        split_frag(hf, sc, H);
+        const bool is_old = p_cur >= 0;
+        row_scale(fmaxf(is_old ? row_max(hf, 0.f) : 0.f, row_max(xf, 0.f)), sc, inv);
+        split_frag(hf, is_old ? sc : 0.f, H);
       } else {
         row_scale(row_max(xf, 0.f), sc, inv);
       }
-      // the next tile's old rows: a whole tile of work ahead of their split
-      p_cur = p_next;
-      load_old(p_cur, vh);
+      // the next tile's old rows go out here, AHEAD of this tile's stores: the memory counter retires in order, so a wait for loads
+      // issued after the stores (as a prefetch at the end of the tile was) waits out the stores' acknowledgements and the loads' whole
+      // latency - with that order the loop ran at ~7 us per tile whatever it computed
+      p_cur = prev_of(t + t_step, p_next);
+      load_old(t + t_step, p_cur, vh);
       p_next = load_prev(t + 2 * t_step);
       split_frag(xf, sc, F);
       const float inv_s = inv * inv_w * -LOG2E, inv_t = inv * inv_w * (-2.0f * LOG2E);
-#pragma unroll
-      for (int ob = 0; ob < NB; ++ob) {
-        f32x4 ar = zero4, az = zero4, ai = zero4, ag = zero4;
+      // The gate loop is software-pipelined by one block: the matrix products of block ob + 1 are issued together with the gate
+      // arithmetic of block ob, and the scheduler is told to alternate them (one MFMA, then vector instructions): a lone vector
+      // instruction costs ~4.5 cycles of the SIMD, but the two waves of a SIMD hide two per MFMA when both streams are finely mixed
+      // (tools/hipcheck/mfma_valu_overlap.hip); long MFMA runs followed by long vector runs did not overlap at all.
+      auto products = [&](int ob, f32x4& ar, f32x4& az, f32x4& ai, f32x4& ag) {
+        ar = zero4; az = zero4; ai = zero4; ag = zero4;
         {
           f32x4 r8 = zero4;
           mma(O_WIH, O_WIH + P_G, L_WIH, 0 * DP + 16 * ob, F, ar, r8);
@@ -377,6 +415,8 @@ __global__ __launch_bounds__(DENSE_T, 2) void dense_split3_kernel(DenseArgs A) {
           mma(O_WHH, O_WHH + P_G, L_WHH, 2 * DP + 16 * ob, H, ag, g8);
           join(ag, g8);
         }
+      };
+      auto gates = [&](int ob, const f32x4& ar, const f32x4& az, const f32x4& ai, const f32x4& ag) {
         const float4 br = *reinterpret_cast<const float4*>(bias_l + 0 * DP + 16 * ob + 4 * hq);
         const float4 bz = *reinterpret_cast<const float4*>(bias_l + 1 * DP + 16 * ob + 4 * hq);
         const float4 bi = *reinterpret_cast<const float4*>(bias_l + 2 * DP + 16 * ob + 4 * hq);
@@ -407,15 +447,155 @@ __global__ __launch_bounds__(DENSE_T, 2) void dense_split3_kernel(DenseArgs A) {
           const float ng = fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(rg, th, ti))), -1.0f);
           hnv[r] = OLD ? fmaf(zg, fmaf(hos[r], inv, -ng), ng) : fmaf(zg, -ng, ng);       // (1 - z) n + z h
         }
-        if (A.probe >= 2) {    // test hook: the gate products themselves (W_in x / W_hn h)
+        if constexpr (PROBE) {    // test hook: the gate products themselves (W_in x / W_hn h)
+          if (A.probe >= 2) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) hnv[r] = (A.probe == 2 ? ai[r] : ag[r]) * (inv * inv_w);
+            for (int r = 0; r < 4; ++r) hnv[r] = (A.probe == 2 ? ai[r] : ag[r]) * (inv * inv_w);
+          }
         }
-        if (node_ok && ((col_ok >> ob) & 1u))
-          (A.hidden_out + row0 * A.ld4)[lane_off + 4 * ob] = make_float4(hnv[0], hnv[1], hnv[2], hnv[3]);
+        const u32x4 bits = {__float_as_uint(hnv[0]), __float_as_uint(hnv[1]), __float_as_uint(hnv[2]), __float_as_uint(hnv[3])};
+        const uint32_t voff = ((col_ok >> ob) & 1u) ? (lane_off + 4u * ob) * 16u : 0xFFFFFFF0u;
+        __builtin_amdgcn_raw_buffer_store_b128(bits, r_out, voff, 0, 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) hn[4 * ob + r] = hnv[r];
+      };
+      f32x4 ar, az, ai, ag;
+      __builtin_amdgcn_sched_barrier(0);
+      products(0, ar, az, ai, ag);
+      if constexpr (PROBE) {
+#pragma unroll
+        for (int ob = 0; ob < NB; ++ob) {
+          gates(ob, ar, az, ai, ag);
+          if (ob + 1 < NB) products(ob + 1, ar, az, ai, ag);
+        }
+      } else {
+        // ---- the pipelined loop, written out at instruction granularity: unit u = one MFMA of block ob + 1's products followed by
+        // at most two vector instructions of block ob's gate arithmetic, pinned by a scheduling barrier (the scheduler left to itself -
+        // also under sched_group_barrier patterns - kept the MFMAs and the transcendentals in separate runs)
+        constexpr int NCALL = OLD ? 6 : 3;                 // products of a block: {W_ih, W_hh} x {r, z}, W_in x, W_hn h
+        constexpr int NU = NCALL * KST * 6;
+        constexpr int OPS_R = OLD ? 19 : 15;               // gate operations per element
+        constexpr int NOPS = 4 + 4 * OPS_R + 1;            // bias reads, 4 elements, the store
+        constexpr int OPU = (NOPS + NU - 1) / NU;          // most vector operations behind one MFMA (the list is spread evenly over the block's MFMAs)
+        static_for<NB>([&](auto OB) {
+          constexpr int ob = decltype(OB)::value;
+          constexpr bool more = ob + 1 < NB;
+          f32x4 nacc[4] = {zero4, zero4, zero4, zero4}, nacc8[4] = {zero4, zero4, zero4, zero4};
+          // gate state of block ob
+          float4 bia[4];
+          float t1[4], t2[4], e1[4], e2[4], rg[4], zg[4], ti[4], th[4], uu[4], e3[4], hm[4], hs[4], ng[4], hnv[4];
+          auto gate_op = [&](auto K) {
+            constexpr int k = decltype(K)::value;
+            if constexpr (k < 4) {
+              bia[k] = *reinterpret_cast<const float4*>(bias_l + k * DP + 16 * ob + 4 * hq);
+              RG_PIN(bia[k].x);
+            } else if constexpr (k < 4 + 4 * OPS_R) {
+              constexpr int j = (k - 4) / 4, r = (k - 4) % 4;          // operation j of element r (operation-major: four independent chains)
+              const float bvr = r == 0 ? bia[0].x : r == 1 ? bia[0].y : r == 2 ? bia[0].z : bia[0].w;
+              const float bvz = r == 0 ? bia[1].x : r == 1 ? bia[1].y : r == 2 ? bia[1].z : bia[1].w;
+              const float bvi = r == 0 ? bia[2].x : r == 1 ? bia[2].y : r == 2 ? bia[2].z : bia[2].w;
+              const float bvh = r == 0 ? bia[3].x : r == 1 ? bia[3].y : r == 2 ? bia[3].z : bia[3].w;
+              constexpr int sH = ob >> 1, jH = 4 * (ob & 1) + (r & ~1);
+              if constexpr (OLD) {
+                if constexpr (j == 0) { t1[r] = fmaf(ar[r], inv_s, bvr); RG_PIN(t1[r]); }
+                else if constexpr (j == 1) { e1[r] = __builtin_amdgcn_exp2f(t1[r]); RG_PIN(e1[r]); }
+                else if constexpr (j == 2) { t2[r] = fmaf(az[r], inv_s, bvz); RG_PIN(t2[r]); }
+                else if constexpr (j == 3) { e2[r] = __builtin_amdgcn_exp2f(t2[r]); RG_PIN(e2[r]); }
+                else if constexpr (j == 4) { t1[r] = 1.0f + e1[r]; RG_PIN(t1[r]); }
+                else if constexpr (j == 5) { t2[r] = 1.0f + e2[r]; RG_PIN(t2[r]); }
+                else if constexpr (j == 6) { rg[r] = __builtin_amdgcn_rcpf(t1[r]); RG_PIN(rg[r]); }
+                else if constexpr (j == 7) { zg[r] = __builtin_amdgcn_rcpf(t2[r]); RG_PIN(zg[r]); }
+                else if constexpr (j == 8) { ti[r] = fmaf(ai[r], inv_t, bvi); RG_PIN(ti[r]); }
+                else if constexpr (j == 9) { th[r] = fmaf(ag[r], inv_t, bvh); RG_PIN(th[r]); }
+                else if constexpr (j == 10) { uu[r] = fmaf(rg[r], th[r], ti[r]); RG_PIN(uu[r]); }
+                else if constexpr (j == 11) { e3[r] = __builtin_amdgcn_exp2f(uu[r]); RG_PIN(e3[r]); }
+                else if constexpr (j == 12) {
+                  const h2 m2 = {H.m[sH][jH], H.m[sH][jH + 1]}, l2 = {H.l[sH][jH], H.l[sH][jH + 1]};
+                  { hm[r] = (r & 1) ? add_hh_hi(m2, l2) : add_hh_lo(m2, l2); RG_PIN(hm[r]); }
+                } else if constexpr (j == 13) { uu[r] = 1.0f + e3[r]; RG_PIN(uu[r]); }
+                else if constexpr (j == 14) {
+                  const h2 h2_ = {H.h[sH][jH], H.h[sH][jH + 1]};
+                  { hs[r] = (r & 1) ? add_hf_hi(h2_, hm[r]) : add_hf_lo(h2_, hm[r]); RG_PIN(hs[r]); }
+                } else if constexpr (j == 15) { e3[r] = __builtin_amdgcn_rcpf(uu[r]); RG_PIN(e3[r]); }
+                else if constexpr (j == 16) { ng[r] = fmaf(2.0f, e3[r], -1.0f); RG_PIN(ng[r]); }
+                else if constexpr (j == 17) { hs[r] = fmaf(hs[r], inv, -ng[r]); RG_PIN(hs[r]); }
+                else { hnv[r] = fmaf(zg[r], hs[r], ng[r]); RG_PIN(hnv[r]); }                       // (1 - z) n + z h
+              } else {
+                if constexpr (j == 0) { t1[r] = fmaf(ar[r], inv_s, bvr); RG_PIN(t1[r]); }
+                else if constexpr (j == 1) { e1[r] = __builtin_amdgcn_exp2f(t1[r]); RG_PIN(e1[r]); }
+                else if constexpr (j == 2) { t2[r] = fmaf(az[r], inv_s, bvz); RG_PIN(t2[r]); }
+                else if constexpr (j == 3) { e2[r] = __builtin_amdgcn_exp2f(t2[r]); RG_PIN(e2[r]); }
+                else if constexpr (j == 4) { t1[r] = 1.0f + e1[r]; RG_PIN(t1[r]); }
+                else if constexpr (j == 5) { t2[r] = 1.0f + e2[r]; RG_PIN(t2[r]); }
+                else if constexpr (j == 6) { rg[r] = __builtin_amdgcn_rcpf(t1[r]); RG_PIN(rg[r]); }
+                else if constexpr (j == 7) { zg[r] = __builtin_amdgcn_rcpf(t2[r]); RG_PIN(zg[r]); }
+                else if constexpr (j == 8) { ti[r] = fmaf(ai[r], inv_t, bvi); RG_PIN(ti[r]); }
+                else if constexpr (j == 9) { uu[r] = fmaf(rg[r], bvh, ti[r]); RG_PIN(uu[r]); }
+                else if constexpr (j == 10) { e3[r] = __builtin_amdgcn_exp2f(uu[r]); RG_PIN(e3[r]); }
+                else if constexpr (j == 11) { uu[r] = 1.0f + e3[r]; RG_PIN(uu[r]); }
+                else if constexpr (j == 12) { e3[r] = __builtin_amdgcn_rcpf(uu[r]); RG_PIN(e3[r]); }
+                else if constexpr (j == 13) { ng[r] = fmaf(2.0f, e3[r], -1.0f); RG_PIN(ng[r]); }
+                else { hnv[r] = fmaf(zg[r], -ng[r], ng[r]); RG_PIN(hnv[r]); }
+              }
+            } else {
+              const u32x4 bits = {__float_as_uint(hnv[0]), __float_as_uint(hnv[1]), __float_as_uint(hnv[2]), __float_as_uint(hnv[3])};
+              const uint32_t voff = ((col_ok >> ob) & 1u) ? (lane_off + 4u * ob) * 16u : 0xFFFFFFF0u;
+              __builtin_amdgcn_raw_buffer_store_b128(bits, r_out, voff, 0, 0);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) hn[4 * ob + r] = hnv[r];
+            }
+          };
+          if constexpr (!more) {
+            static_for<NOPS>(gate_op);
+          } else {
+            typedef long lk __attribute__((ext_vector_type(KST)));
+            h8 wh, wm_, nwh, nwm;
+            lk wl, nwl;
+            // fragment reads of product c, k-step s of block ob + 1
+            auto fetch = [&](auto C, auto S_, h8& fh, h8& fm, lk& fl) {
+              constexpr int c = decltype(C)::value, ks = decltype(S_)::value;
+              constexpr bool isH = OLD && (c & 1);
+              constexpr int gate = OLD ? c / 2 : c;
+              constexpr uint32_t row_b = (uint32_t)(gate * DP + 16 * (ob + 1)) * SR;
+              constexpr uint32_t o_hi = (isH ? O_WHH : O_WIH) + row_b * 16u, o_mid = o_hi + P_G, o_lo = (isH ? L_WHH : L_WIH) + row_b * 8u;
+              fh = o_hi < 65536u ? *reinterpret_cast<const h8*>(wbase + (a_off[ks] + o_hi)) : *reinterpret_cast<const h8*>(wbase + (b_off[ks] + (o_hi - 65536u)));
+              fm = o_mid < 65536u ? *reinterpret_cast<const h8*>(wbase + (a_off[ks] + o_mid)) : *reinterpret_cast<const h8*>(wbase + (b_off[ks] + (o_mid - 65536u)));
+              if constexpr (ks == 0) fl = *reinterpret_cast<const lk*>(wbase + (c_off + o_lo));
+            };
+            fetch(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, nwh, nwm, nwl);
+            static_for<NU>([&](auto U) {
+              constexpr int u = decltype(U)::value;
+              constexpr int c = u / (6 * KST), ks = (u / 6) % KST, term = u % 6;
+              constexpr bool isH = OLD && (c & 1);
+              constexpr int gate = OLD ? c / 2 : c;
+              constexpr int ai_ = (isH && gate == 2) ? 3 : gate;
+              const Frag<KST>& X = isH ? H : F;
+              if constexpr (term == 0) {
+                wh = nwh; wm_ = nwm;
+                if constexpr (ks == 0) wl = nwl;
+                constexpr int nk = u / 6 + 1;                  // the next k-step's fragments go out now
+                if constexpr (nk < NCALL * KST) fetch(std::integral_constant<int, nk / KST>{}, std::integral_constant<int, nk % KST>{}, nwh, nwm, nwl);
+                nacc8[ai_] = __builtin_amdgcn_mfma_f32_16x16x32_bf8_bf8(wl[ks], X.q[ks], nacc8[ai_], 0, 0, 0);
+              } else if constexpr (term == 1) nacc[ai_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, X.l[ks], nacc[ai_], 0, 0, 0);
+              else if constexpr (term == 2) nacc[ai_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wm_, X.m[ks], nacc[ai_], 0, 0, 0);
+              else if constexpr (term == 3) nacc[ai_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wm_, X.h[ks], nacc[ai_], 0, 0, 0);
+              else if constexpr (term == 4) nacc[ai_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, X.m[ks], nacc[ai_], 0, 0, 0);
+              else nacc[ai_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, X.h[ks], nacc[ai_], 0, 0, 0);
+              if constexpr (term == 0) RG_PIN(nacc8[ai_]); else RG_PIN(nacc[ai_]);
+              static_for<OPU>([&](auto Q) {
+                constexpr int k_lo = (u * NOPS + NU - 1) / NU, k_hi = ((u + 1) * NOPS + NU - 1) / NU, k = k_lo + decltype(Q)::value;
+                if constexpr (k < k_hi) gate_op(std::integral_constant<int, k>{});
+              });
+              __builtin_amdgcn_sched_barrier(0);
+            });
+#pragma unroll
+            for (int g = 0; g < 4; ++g) join(nacc[g], nacc8[g]);
+            ar = nacc[0]; az = nacc[1]; ai = nacc[2]; ag = nacc[3];
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        });
       }
+      __builtin_amdgcn_sched_barrier(0);
     };
     if (any_old) gru(std::true_type{}); else gru(std::false_type{});
 
@@ -427,14 +607,16 @@ __global__ __launch_bounds__(DENSE_T, 2) void dense_split3_kernel(DenseArgs A) {
       mma(O_E, O_E + P_E, L_E, 0, F, acc, acc8);
       join(acc, acc8);
       const float sc_e = inv_we * inv_n;
-      if (node_ok && 4 * hq < A.ap)
-        reinterpret_cast<float4*>(A.a_s_out + node * A.ap)[hq] = make_float4(acc[0] * sc_e, acc[1] * sc_e, acc[2] * sc_e, acc[3] * sc_e);
+      const __amdgpu_buffer_rsrc_t r_as = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(A.a_s_out + row0 * A.ap), 0,
+                                                                            rows_valid * A.ap * 4, 0x00020000);
+      const u32x4 bits = {__float_as_uint(acc[0] * sc_e), __float_as_uint(acc[1] * sc_e), __float_as_uint(acc[2] * sc_e), __float_as_uint(acc[3] * sc_e)};
+      __builtin_amdgcn_raw_buffer_store_b128(bits, r_as, 4 * hq < A.ap ? (uint32_t)(li * A.ap + 4 * hq) * 4u : 0xFFFFFFF0u, 0, 0);
     }
     if (A.W_final) {  // row 16 = register 0 of quarter 0 of block 1
       f32x4 acc = zero4, acc8 = zero4;
       mma(O_E, O_E + P_E, L_E, 16, F, acc, acc8);
       join(acc, acc8);
-      if (node_ok && hq == 0) A.scores[(int64_t)qe.x * A.n_ent + qe.y] = acc[0] * (inv_we * inv_n);
+      if (node_ok && hq == 0) A.scores[score_at] = acc[0] * (inv_we * inv_n);
     }
   }
 }
@@ -445,22 +627,23 @@ constexpr size_t lds_bytes() {
   return (size_t)(14 * DP * SR + 2 * 32 * SR) * 16 + (size_t)(7 * DP * SR + 32 * SR) * 8 + 4 * DP * sizeof(float) + 16;   // + the two maxima
 }
 
-template <int NB, int ACT>
+template <int NB, int ACT, bool PROBE>
 int launch(const DenseArgs& A, hipStream_t s) {
   constexpr int NW = DENSE_T / 64;
   constexpr size_t lds = lds_bytes<NB>();
   static_assert(lds <= 160 * 1024, "weight images exceed the CU's LDS");
-  RG_HIP(hipFuncSetAttribute((const void*)dense_split3_kernel<NB, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  RG_HIP(hipFuncSetAttribute((const void*)dense_split3_kernel<NB, ACT, PROBE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int64_t tiles = A.n_dev && A.n_hint > 0 ? std::min<int64_t>(A.n_tiles, rg::ceil_div(A.n_hint + A.n_hint / 4, 16)) : A.n_tiles;
   const int grid = (int)std::max<int64_t>(std::min<int64_t>(rg::ceil_div(tiles, NW), 256), 1);
-  hipLaunchKernelGGL((dense_split3_kernel<NB, ACT>), dim3(grid), dim3(DENSE_T), lds, s, A);
+  hipLaunchKernelGGL((dense_split3_kernel<NB, ACT, PROBE>), dim3(grid), dim3(DENSE_T), lds, s, A);
   RG_LAUNCH_CHECK();
   return 0;
 }
 
 template <int NB>
 int launch_act(const DenseArgs& A, hipStream_t s) {
-  return A.act == 0 ? launch<NB, 0>(A, s) : A.act == 1 ? launch<NB, 1>(A, s) : launch<NB, 2>(A, s);
+  if (A.probe) return launch<NB, 0, true>(A, s);        // (the hook runs with the identity activation)
+  return A.act == 0 ? launch<NB, 0, false>(A, s) : A.act == 1 ? launch<NB, 1, false>(A, s) : launch<NB, 2, false>(A, s);
 }
 
 // rg_split3_roundtrip: the device split of n rows of `cols` floats (row scale as the kernels take it) and its reconstruction
