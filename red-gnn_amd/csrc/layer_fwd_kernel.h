@@ -75,7 +75,7 @@ __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0
 constexpr int FWD_BLOCK = 512;   // 3 workgroups per CU = 24 waves at <= 80 VGPRs (no spills)
 
 template <int G, int AP4, bool PACKED, bool DENSE, int KPG, bool RELA_LDS, bool TEMPORAL>
-__global__ __launch_bounds__(FWD_BLOCK, TEMPORAL ? (AP4 >= 8 ? 2 : 4) : (G >= 32 ? 4 : 6)) void layer_fwd_kernel(FwdArgs A) {
+__global__ __launch_bounds__(FWD_BLOCK, TEMPORAL ? 4 : (G >= 32 ? 4 : 6)) void layer_fwd_kernel(FwdArgs A) {
   extern __shared__ float4 lds[];
   constexpr int BLOCK = FWD_BLOCK;
   float4* stage = lds;                                   // [BLOCK] edge tuples {s, r, alpha, -}
@@ -147,7 +147,9 @@ __global__ __launch_bounds__(FWD_BLOCK, TEMPORAL ? (AP4 >= 8 ? 2 : 4) : (G >= 32
         if (valid) {
           s = wp.y + __popc(word & ((1u << bit) - 1u));
           float z = b_alpha;
-#pragma unroll
+          // (a 32-wide attention row fully unrolled keeps sixteen loads live: 182 registers, two waves per SIMD; two steps at a time fit
+          // 112 and four waves - same order of the sum)
+#pragma unroll(AP4 >= 8 ? 2 : AP4)
           for (int k = 0; k < AP4; ++k) {
             const float4 as = A.a_s[(int64_t)s * AP4 + k];
             const float4 ar = ar_l[r * AP4 + k];

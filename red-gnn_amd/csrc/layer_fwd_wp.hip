@@ -28,6 +28,10 @@ namespace rgwp {
 namespace {
 
 constexpr int WP_BLOCK = 512, WP_WAVES = WP_BLOCK / 64;
+// (four waves per SIMD = two workgroups per CU: the kernel waits 75 % of its wave cycles on C3's late hops - 23 % VALU-busy, 10.8
+// wave-instructions per edge, profiles/r03/pmc_wp_issue_C3_B256_summary.json - but six / eight waves per SIMD were SLOWER on every hop of
+// C3 (2.53 -> 2.64 / 2.85 ms on hop 4), of C2 (hop 1 1.73 -> 2.98 / 3.17 ms) and on family (338 k -> 326 k / 313 k queries/s): more
+// waves are more query groups' source rows competing for an XCD's L2)
 constexpr int QCAP = 256;   // queued edges per wave between flushes; >= RG_PACK, so one query's edges of a pack always fit
 constexpr int WAVE_LDS = QCAP * 16 + 64;     // bytes: tuples [QCAP] (the 8-B fill queue aliases their upper half) + 4 head masks
 static_assert(QCAP == 256 && RG_PACK == 128, "a lane holds two entries of a pack; phase 1 runs as two trips of 128 queued edges");

@@ -8,7 +8,7 @@ from red_gnn_amd.load_data import DataLoader
 
 ids = dict(np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "family_ids.npz")))
 loader = DataLoader(ids=ids, verbose=False)
-for walk in (0, 1, 4, 5, 0):
+for walk in (0, 3, 4, 5, 6, 0):
     class Opt:
         lr, decay_rate, lamb, hidden_dim, attn_dim, n_layer, dropout, act, n_batch, n_tbatch = 0.0036, 0.999, 1.7e-5, 64, 5, 3, 0.29, "relu", 20, 50
         n_rel = loader.n_rel
