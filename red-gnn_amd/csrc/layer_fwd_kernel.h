@@ -149,7 +149,7 @@ __global__ __launch_bounds__(FWD_BLOCK, TEMPORAL ? 4 : (G >= 32 ? 4 : 6)) void l
           float z = b_alpha;
           // (a 32-wide attention row fully unrolled keeps sixteen loads live: 182 registers, two waves per SIMD; two steps at a time fit
           // 112 and four waves - same order of the sum)
-#pragma unroll(AP4 >= 8 ? 2 : AP4)
+#pragma clang loop unroll_count(AP4 >= 8 ? 2 : AP4)
           for (int k = 0; k < AP4; ++k) {
             const float4 as = A.a_s[(int64_t)s * AP4 + k];
             const float4 ar = ar_l[r * AP4 + k];

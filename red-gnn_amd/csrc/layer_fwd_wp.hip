@@ -280,13 +280,13 @@ __global__ __launch_bounds__(WP_BLOCK, 4) void layer_fwd_wp_kernel(WpArgs A) {
   // ---- work distribution: XCD x serves the x-th eighth of the items from its own in-order queue, A.ipt items per ticket and wave;
   // a wave whose queue is dry steals from the others (speed only: every item is taken exactly once under any placement)
   int q = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7;   // HW_REG_XCC_ID
-  int n_dry = 0;
   auto ticket = [&]() -> int {
     int off = 0;
     if (lane == 0) off = atomicAdd(&A.queues[q * RG_QSTRIDE], A.ipt);
     return off;
   };
-  // lane 0's ticket -> (first item, count) for the whole wave; count 0 = every queue is dry
+  // lane 0's ticket -> (first item, count) for the whole wave; count 0 = every queue is dry.  A dry queue is followed by one look at all
+  // eight heads (lanes 0..7, one round trip) and a ticket from the first queue that still has items (cf. walk.h)
   auto resolve = [&](int off, long long* first) -> int {
     off = __builtin_amdgcn_readfirstlane(off);
     for (;;) {
@@ -295,8 +295,12 @@ __global__ __launch_bounds__(WP_BLOCK, 4) void layer_fwd_wp_kernel(WpArgs A) {
         *first = qs + off;
         return (int)min((long long)A.ipt, ql - off);
       }
-      q = (q + 1) & 7;
-      if (++n_dry == 8) return 0;
+      const int k = (q + 1 + lane) & 7;                   // lanes 0..6: the other queues in stealing order
+      bool has = false;
+      if (lane < 7) has = __hip_atomic_load(&A.queues[k * RG_QSTRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < A.n_items * (k + 1) / 8 - A.n_items * k / 8;
+      const unsigned long long m = __ballot(has);
+      if (m == 0ull) return 0;                            // (heads only grow: dry stays dry)
+      q = (q + 1 + (__ffsll((long long)m) - 1)) & 7;
       off = __builtin_amdgcn_readfirstlane(ticket());
     }
   };

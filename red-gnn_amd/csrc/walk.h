@@ -61,8 +61,9 @@ __device__ __forceinline__ void walk_items(const WalkArgs& A, int4* recs, F&& ru
 
   __shared__ int slot[2][4];   // {b0, vr0, count} of the step's first item
   int q = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7;   // HW_REG_XCC_ID: speed only
-  int n_dry = 0;
-  // thread 0: turn ticket `off` of queue q into a slot (or steal); count 0 = every queue is dry
+  // thread 0: turn ticket `off` of queue q into a slot (or steal); count 0 = every queue is dry.  A dry queue is followed by ONE look at
+  // all eight heads (independent loads, one round trip) and a ticket from the first queue that still has items: drawing a ticket from each
+  // queue in turn was up to seven dependent returning atomics at the tail of every launch (20 us of a 50-query hop)
   auto resolve = [&](int off, int* out) {
     for (;;) {
       const int64_t qs = A.n_items * q / 8, ql = A.n_items * (q + 1) / 8 - qs;
@@ -72,8 +73,17 @@ __device__ __forceinline__ void walk_items(const WalkArgs& A, int4* recs, F&& ru
         out[0] = b0; out[1] = (int)(item - (int64_t)b0 * A.n_vrows); out[2] = (int)min((int64_t)STEP, ql - off);
         return;
       }
-      q = (q + 1) & 7;
-      if (++n_dry == 8) { out[2] = 0; return; }
+      int head[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) head[k] = __hip_atomic_load(&A.queues[k * RG_QSTRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int best = -1;
+#pragma unroll
+      for (int j = 7; j >= 1; --j) {
+        const int k = (q + j) & 7;
+        if (head[k] < A.n_items * (k + 1) / 8 - A.n_items * k / 8) best = k;
+      }
+      if (best < 0) { out[2] = 0; return; }      // (heads only grow: dry stays dry)
+      q = best;
       off = atomicAdd(&A.queues[q * RG_QSTRIDE], STEP);
     }
   };
