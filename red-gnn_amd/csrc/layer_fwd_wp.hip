@@ -34,7 +34,7 @@ constexpr int WP_BLOCK = 512, WP_WAVES = WP_BLOCK / 64;
 // waves are more query groups' source rows competing for an XCD's L2)
 constexpr int QCAP = 256;   // queued edges per wave between flushes; >= RG_PACK, so one query's edges of a pack always fit
 constexpr int WAVE_LDS = QCAP * 16 + 64;     // bytes: tuples [QCAP] (the 8-B fill queue aliases their upper half) + 4 head masks
-static_assert(QCAP == 256 && RG_PACK == 128, "a lane holds two entries of a pack; phase 1 runs as two trips of 128 queued edges");
+static_assert(QCAP == 256 && RG_PACK == 128, "a lane holds two entries of a pack; phase 1 takes four queued edges per lane");
 
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
@@ -160,44 +160,48 @@ __global__ __launch_bounds__(WP_BLOCK, 4) void layer_fwd_wp_kernel(WpArgs A) {
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      // ---- phase 1: queued edges -> tuples, two per lane and trip (their load chains overlap) --------------------------
+      // ---- phase 1: queued edges -> tuples, up to four per lane at once: their dependent load chains (frontier words and row records,
+      // then the destination's word and the source's attention row) run side by side (two trips of two were 29 % of the kernel's cycles
+      // on C2's second hop: one trip waited out the other's chains) ---------------------------------------------------------------
+      {
+        int2 en[4];
+        int s[4], out[4];
+        bool valid[4];
 #pragma unroll
-      for (int trip = 0; trip < 2; ++trip) {
-        const int i0 = trip * 128;
-        if (i0 >= qn) {
-          if (lane == 0) { hmask[2 * trip] = 0ull; hmask[2 * trip + 1] = 0ull; }
-          continue;
-        }
-        int2 en[2];
-        int s[2], out[2];
-        bool valid[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int i = i0 + j * 64 + lane;
+        for (int j = 0; j < 4; ++j) {
+          const int i = j * 64 + lane;
           valid[j] = i < qn;
           en[j] = valid[j] ? q8[i] : make_int2(0, -1);
           const int prev_key = (valid[j] && i > 0) ? q8[i - 1].y : -2;
           const unsigned long long hm = __ballot(valid[j] && en[j].y != prev_key);
-          if (lane == 0) hmask[2 * trip + j] = hm;
+          if (lane == 0) hmask[j] = hm;
+        }
+        int2 wp[4], dst[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          wp[j] = make_int2(0, 0); dst[j] = make_int2(0, 0);
+          if (valid[j]) {
+            const int hd = en[j].x & 0xFFFFF, bq = bw * 32 + (en[j].y >> 8);
+            wp[j] = A.bm_old[(int64_t)bq * A.W + (hd >> 5)];
+            dst[j] = A.rows[row0 + (en[j].y & 255)];                  // {entity, slot of a cut row's partial sum or -1}
+          }
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < 4; ++j) {
           s[j] = 0; out[j] = 0;
           if (valid[j]) {
             const int hd = en[j].x & 0xFFFFF, bq = bw * 32 + (en[j].y >> 8);
-            const int2 wp = A.bm_old[(int64_t)bq * A.W + (hd >> 5)];
-            const int2 dst = A.rows[row0 + (en[j].y & 255)];                  // {entity, slot of a cut row's partial sum or -1}
-            s[j] = wp.y + __popc((uint32_t)wp.x & ((1u << (hd & 31)) - 1u));
-            if (dst.y < 0) {
-              const int2 wn = A.bm_new[(int64_t)bq * A.W + (dst.x >> 5)];
-              out[j] = wn.y + __popc((uint32_t)wn.x & ((1u << (dst.x & 31)) - 1u));
+            s[j] = wp[j].y + __popc((uint32_t)wp[j].x & ((1u << (hd & 31)) - 1u));
+            if (dst[j].y < 0) {
+              const int2 wn = A.bm_new[(int64_t)bq * A.W + (dst[j].x >> 5)];
+              out[j] = wn.y + __popc((uint32_t)wn.x & ((1u << (dst[j].x & 31)) - 1u));
             } else {
-              out[j] = -(bq * A.n_slots + dst.y) - 1;
+              out[j] = -(bq * A.n_slots + dst[j].y) - 1;
             }
           }
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < 4; ++j) {
           if (valid[j]) {
             const int r = (uint32_t)en[j].x >> 20;
             const float4* aq_p = A.a_q + (int64_t)(bw * 32 + (en[j].y >> 8)) * AP4;
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(WP_BLOCK, 4) void layer_fwd_wp_kernel(WpArgs A) {
             const float alpha = __builtin_amdgcn_rcpf(1.0f + __expf(-z));
             const uint32_t hoff = (uint32_t)s[j] * row_bytes;                 // < 2^32: checked by the launcher
             const uint32_t roff = (uint32_t)r * (RELA_LDS ? (uint32_t)(RW * 16) : row_bytes);
-            st[i0 + j * 64 + lane] = make_float4(__int_as_float((int)hoff), __int_as_float((int)roff), alpha, __int_as_float(out[j]));
+            st[j * 64 + lane] = make_float4(__int_as_float((int)hoff), __int_as_float((int)roff), alpha, __int_as_float(out[j]));
           }
         }
       }
