@@ -245,10 +245,11 @@ def family_eval(dist, world, engine, cpu_leg=True, rank=0):
         loader = DataLoader(ids=ids, verbose=False)
         nq = loader.n_valid + loader.n_test
 
-        def build(n_tb):
+        def build(n_tb, coalesce=1):
             class Opt:
                 lr, decay_rate, lamb, hidden_dim, attn_dim, n_layer, dropout, act, n_batch, n_tbatch = 0.0036, 0.999, 1.7e-5, 64, 5, 3, 0.29, "relu", 20, n_tb
                 n_rel = loader.n_rel
+                eval_coalesce = coalesce
 
             torch.manual_seed(1234)
             return BaseModel(Opt, loader, dist=dist if world > 1 else None)
@@ -293,8 +294,11 @@ def family_eval(dist, world, engine, cpu_leg=True, rank=0):
         if cpu_leg and world == 1 and rank == 0:
             out["cpu_baseline"], out["parity"] = family_cpu_leg(bm, loader, ids)
             out["speedup_vs_cpu_edges_per_s"] = out["edges_per_s"] / out["cpu_baseline"]["value"]
-        qps_500, _, mrr_500 = measure(build(500), 5)      # the same evaluation in batches of 500 (not the reference's setting: for scale only)
-        out.update(queries_per_s_at_n_tbatch_500=qps_500, same_mrr_at_n_tbatch_500=abs(mrr - mrr_500) < 1e-9)
+        # the same evaluation with ten reference batches fused per forward pass (BaseModel.eval_coalesce: a query's scores do not depend
+        # on the rest of its batch - same scores, same ranks; not what the reference does per pass, so it is not the headline figure)
+        qps_500, _, mrr_500 = measure(build(50, coalesce=10), 5)
+        out.update(queries_per_s_at_n_tbatch_500=qps_500, same_mrr_at_n_tbatch_500=abs(mrr - mrr_500) < 1e-9,
+                   queries_per_s_eval_coalesce_10=qps_500)
         return out
     finally:
         engine.KERNEL_EVENTS, engine.DENSE_EVENTS = saved

@@ -63,6 +63,11 @@ class BaseModel(object):
             setattr(self, name, getattr(loader, name))
         for name in ("n_batch", "n_tbatch", "n_layer"):
             setattr(self, name, getattr(args, name))
+        # evaluation batches fused per forward pass.  A query's scores do not depend on the other queries of its batch (nodes are
+        # (query, entity) pairs and every sum is taken per node in CSR order), so k reference batches of n_tbatch evaluated as ONE pass
+        # of k * n_tbatch queries give the same scores bit for bit and the same ranks; n_tbatch then only bounds memory, as in the
+        # reference.  1 = one pass per reference batch (the default: what the reference does).
+        self.eval_coalesce = max(1, int(getattr(args, "eval_coalesce", 1)))
         # fused=True: one multi-tensor kernel for all parameters (same update rule; the default issues a dozen launches)
         self.optimizer = Adam(self.model.parameters(), lr=args.lr, weight_decay=args.lamb, fused=True)
         self.scheduler = ExponentialLR(self.optimizer, args.decay_rate)
@@ -141,7 +146,7 @@ class BaseModel(object):
         m = self.model
         n_ent = max(int(getattr(self.loader, "n_ent", 0)), int(getattr(self.loader, "n_ent_ind", 0)), 1)
         try:
-            need = _GraphedInference.bytes_needed(self.n_tbatch, n_ent, max(16, _pad4(m.hidden_dim)), pad_attn(m.attn_dim))
+            need = _GraphedInference.bytes_needed(self.n_tbatch * self.eval_coalesce, n_ent, max(16, _pad4(m.hidden_dim)), pad_attn(m.attn_dim))
         except (AttributeError, ValueError):        # a model without the replayed forward
             need = 0
         budget = _GraphedInference.budget(next(m.parameters()).device)
@@ -157,7 +162,7 @@ class BaseModel(object):
         captured forward graph (own buffers) and ranks on its stream; the lanes run concurrently on the device."""
         mode = self.loader.eval_mode(data) if hasattr(self.loader, "eval_mode") else data
         device = next(self.model.parameters()).device
-        batches = _chunks(n_data, self.n_tbatch)[self.rank::self.world]             # evaluation batches dealt round-robin
+        batches = _chunks(n_data, self.n_tbatch * self.eval_coalesce)[self.rank::self.world]             # evaluation batches dealt round-robin
         n_lanes = self._eval_lanes(len(batches))
         main = torch.cuda.current_stream(device)
         if n_lanes > 1:

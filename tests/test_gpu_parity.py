@@ -1138,6 +1138,34 @@ def test_evaluation_lanes_give_the_same_metrics():
     assert len(bm.model._graphed) >= 8
 
 
+def test_evaluation_batches_fused_per_pass_give_the_same_scores_and_ranks():
+    """BaseModel.eval_coalesce = k evaluates k reference batches of n_tbatch as one forward pass: a query's scores do not depend on the
+    other queries of its batch, so the scores are the same BIT FOR BIT and the ranks identical (partial last batches included)."""
+    from red_gnn_amd.base_model import BaseModel
+    from red_gnn_amd.load_data import DataLoader
+    ids = U.load("family_ids.npz")
+    loader = DataLoader(ids=ids, verbose=False)
+
+    class Opt:
+        lr, decay_rate, lamb, hidden_dim, attn_dim, n_layer, dropout, act, n_batch, n_tbatch = 0.0036, 0.999, 1.7e-5, 64, 5, 3, 0.1, "relu", 20, 50
+        n_rel = loader.n_rel
+
+    torch.manual_seed(11)
+    bm = BaseModel(Opt, loader)
+    bm.n_valid = 430                                      # 8 full batches and one of 30
+    bm.model.eval()
+    ref = bm._rank_split("valid", bm.n_valid).cpu().numpy()
+    for k in (3, 4):
+        bm.eval_coalesce = k
+        for _ in range(3):                                # eager, capture, replay
+            assert np.array_equal(bm._rank_split("valid", bm.n_valid).cpu().numpy(), ref), k
+    # scores of the first 200 queries: four passes of 50 against one of 200
+    with torch.no_grad():
+        parts = [bm.model(*loader.get_batch_csr(np.arange(i, i + 50), data="valid")[:2], mode="valid") for i in range(0, 200, 50)]
+        whole = bm.model(*loader.get_batch_csr(np.arange(200), data="valid")[:2], mode="valid")
+    assert torch.equal(torch.cat(parts), whole)
+
+
 def test_inductive_training_learns():
     """The reference's loop in the inductive setting (train on the transductive graph's valid triples, evaluate the
     'test' split on the inductive graph with its own entity set): one short epoch lifts the inductive MRR."""
