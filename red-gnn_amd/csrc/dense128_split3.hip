@@ -15,6 +15,7 @@
 //          quarter hq (8 bytes each): a ds_read_b128 per half, whose lane groups cover the 64 banks
 //   blocks 0..7 W_h, 8 + 8 g + ob weight_ih, 32 + 8 g + ob weight_hh (gate g, output block ob), 56 Ws (rows < attn), 57 W_final (row 0).
 #include <type_traits>
+#include <utility>
 #include "dense_common.h"
 #include "split3.h"
 
@@ -24,6 +25,14 @@ namespace {
 using namespace rg::sp3;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef long l2v __attribute__((ext_vector_type(2)));
+
+#define RG_PIN(x) asm volatile("" : "+v"(x))      // see dense_split3.hip: pins the order of the instruction that produced x
+#define RG_PIN_ACC(x) asm volatile("" : "+a"(x))  // the same for an MFMA accumulator, which lives in the accumulation registers here
+
+template <class Fn, int... I>
+__device__ __forceinline__ void static_for_impl(Fn&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class Fn>
+__device__ __forceinline__ void static_for(Fn&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 constexpr int DP = 128, NB = 8, KST = 4, KS = 32, NW = 4, T = 256;
 constexpr int S = 32;                       // float4 per row of the node buffers
@@ -178,6 +187,39 @@ __global__ __launch_bounds__(T, 1) void dense128_split3_kernel(DenseArgs A, cons
 #pragma unroll
       for (int j = 0; j < 3; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], X.h[s], c[j], 0, 0, 0);
     }
+  };
+  // mma3 with vector operations of the PREVIOUS output block's gate arithmetic placed behind its MFMAs, one MFMA at a time (a wave
+  // alone on its SIMD pays 7 counter ticks per vector instruction in a vector-only stretch and ~2.5 behind an MFMA:
+  // tools/hipcheck/mfma_valu_roles.hip): op(k) for k in [k0, k1), spread evenly over the 72 MFMAs
+  auto mma3_ops = [&](const Frag4& X, f32x4 (&c)[3], f32x4 (&e)[3], auto K0, auto K1, auto&& op) {
+    constexpr int k0 = decltype(K0)::value, k1 = decltype(K1)::value, NM = 18 * KST;
+    const char* wb = wbuf + cur * CHUNK_B;
+    l2v wl[3][2];
+    h8 wh[3], wm[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      wl[j][0] = *reinterpret_cast<const l2v*>(wb + j * BLK_B + c_off[0]);
+      wl[j][1] = *reinterpret_cast<const l2v*>(wb + j * BLK_B + c_off[1]);
+    }
+    static_for<NM>([&](auto M) {
+      constexpr int m = decltype(M)::value, s_ = m / 18, term = (m % 18) / 3, j = m % 3;
+      if constexpr (m % 18 == 0) {
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj) {
+          wh[jj] = *reinterpret_cast<const h8*>(wb + jj * BLK_B + a_off[s_]);
+          wm[jj] = *reinterpret_cast<const h8*>(wb + jj * BLK_B + F16_B + a_off[s_]);
+        }
+      }
+      if constexpr (term == 0) { e[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf8_bf8(wl[j][s_ >> 1][s_ & 1], X.q[s_], e[j], 0, 0, 0); RG_PIN_ACC(e[j]); }
+      else if constexpr (term == 1) { c[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], X.l[s_], c[j], 0, 0, 0); RG_PIN_ACC(c[j]); }
+      else if constexpr (term == 2) { c[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wm[j], X.m[s_], c[j], 0, 0, 0); RG_PIN_ACC(c[j]); }
+      else if constexpr (term == 3) { c[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wm[j], X.h[s_], c[j], 0, 0, 0); RG_PIN_ACC(c[j]); }
+      else if constexpr (term == 4) { c[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], X.m[s_], c[j], 0, 0, 0); RG_PIN_ACC(c[j]); }
+      else { c[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], X.h[s_], c[j], 0, 0, 0); RG_PIN_ACC(c[j]); }
+      constexpr int a = k0 + (m * (k1 - k0)) / NM, b = k0 + ((m + 1) * (k1 - k0)) / NM;
+      static_for<b - a>([&](auto Q) { op(std::integral_constant<int, a + decltype(Q)::value>{}); });
+      __builtin_amdgcn_sched_barrier(0);
+    });
   };
   auto join = [&](f32x4& acc, const f32x4& acc8) {
 #pragma unroll
@@ -336,50 +378,91 @@ __global__ __launch_bounds__(T, 1) void dense128_split3_kernel(DenseArgs A, cons
     split_frag(xf, sc, X);
     const float inv_s = inv * inv_w * -LOG2E, inv_t = inv * inv_w * (-2.0f * LOG2E);
     float hn[KS];
+    // new-state rows go out through a buffer descriptor of this tile's valid rows (no branch inside the interleaved stream)
+    const int rows_valid = (int)(A.n - row0 < 16 ? (A.n - row0 > 0 ? A.n - row0 : 0) : 16);
+    const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(A.hidden_out + row0 * S), 0,
+                                                                            rows_valid * S * 16, 0x00020000);
+    // The loop over output blocks is software-pipelined by one block: the gate arithmetic of block ob - 1 (joins of the bf8 chains, the
+    // three gates, the new state and its store: 105 operations) is issued between the MFMAs of block ob's two chunks.
+    auto gate_loop = [&](auto HH_) {
+      constexpr bool HH = decltype(HH_)::value;
+      f32x4 P[2][4][3];                               // [block parity][c (r, z, W_in x), e (their bf8 chains), cg (r, z, W_hn h), eg][3]
+      static_for<NB + 1>([&](auto OB) {
+        constexpr int ob = decltype(OB)::value, cs = ob & 1, ps = cs ^ 1, pb = ob - 1;
+        constexpr int OPS_R = 25, NOPS = 4 + 4 * OPS_R + 1;
+        float4 bia[4];
+        float s1[4], a1[4], ar[4], az[4], ai[4], ag[4], t1[4], t2[4], e1[4], e2[4], rg[4], zg[4], ti[4], th[4], uu[4], e3[4], ng[4], hnv[4];
+        auto gate_op = [&](auto K) {
+          constexpr int k = decltype(K)::value;
+          f32x4 (&c)[3] = P[ps][0]; f32x4 (&e)[3] = P[ps][1]; f32x4 (&cg)[3] = P[ps][2]; f32x4 (&eg)[3] = P[ps][3];
+          if constexpr (k < 4) {
+            bia[k] = *reinterpret_cast<const float4*>(bias_l + k * DP + 16 * pb + 4 * hq);
+            RG_PIN(bia[k].x);
+          } else if constexpr (k < 4 + 4 * OPS_R) {
+            constexpr int j = (k - 4) / 4, r = (k - 4) % 4;
+            const float bvr = r == 0 ? bia[0].x : r == 1 ? bia[0].y : r == 2 ? bia[0].z : bia[0].w;
+            const float bvz = r == 0 ? bia[1].x : r == 1 ? bia[1].y : r == 2 ? bia[1].z : bia[1].w;
+            const float bvi = r == 0 ? bia[2].x : r == 1 ? bia[2].y : r == 2 ? bia[2].z : bia[2].w;
+            const float bvh = r == 0 ? bia[3].x : r == 1 ? bia[3].y : r == 2 ? bia[3].z : bia[3].w;
+            // r and z gates: W_i. x + W_h. h in one sum (f16 chains added, bf8 chains added and joined); the n gate keeps its products apart
+            if constexpr (j == 0) { s1[r] = HH ? e[0][r] + eg[0][r] : e[0][r]; RG_PIN(s1[r]); }
+            else if constexpr (j == 1) { a1[r] = HH ? c[0][r] + cg[0][r] : c[0][r]; RG_PIN(a1[r]); }
+            else if constexpr (j == 2) { ar[r] = fmaf(s1[r], LO8_INV, a1[r]); RG_PIN(ar[r]); }
+            else if constexpr (j == 3) { s1[r] = HH ? e[1][r] + eg[1][r] : e[1][r]; RG_PIN(s1[r]); }
+            else if constexpr (j == 4) { a1[r] = HH ? c[1][r] + cg[1][r] : c[1][r]; RG_PIN(a1[r]); }
+            else if constexpr (j == 5) { az[r] = fmaf(s1[r], LO8_INV, a1[r]); RG_PIN(az[r]); }
+            else if constexpr (j == 6) { ai[r] = fmaf(e[2][r], LO8_INV, c[2][r]); RG_PIN(ai[r]); }
+            else if constexpr (j == 7) { ag[r] = HH ? fmaf(eg[2][r], LO8_INV, cg[2][r]) : 0.f; RG_PIN(ag[r]); }
+            else if constexpr (j == 8) { t1[r] = fmaf(ar[r], inv_s, bvr); RG_PIN(t1[r]); }
+            else if constexpr (j == 9) { e1[r] = __builtin_amdgcn_exp2f(t1[r]); RG_PIN(e1[r]); }
+            else if constexpr (j == 10) { t2[r] = fmaf(az[r], inv_s, bvz); RG_PIN(t2[r]); }
+            else if constexpr (j == 11) { e2[r] = __builtin_amdgcn_exp2f(t2[r]); RG_PIN(e2[r]); }
+            else if constexpr (j == 12) { t1[r] = 1.0f + e1[r]; RG_PIN(t1[r]); }
+            else if constexpr (j == 13) { t2[r] = 1.0f + e2[r]; RG_PIN(t2[r]); }
+            else if constexpr (j == 14) { rg[r] = __builtin_amdgcn_rcpf(t1[r]); RG_PIN(rg[r]); }
+            else if constexpr (j == 15) { zg[r] = __builtin_amdgcn_rcpf(t2[r]); RG_PIN(zg[r]); }
+            else if constexpr (j == 16) { ti[r] = fmaf(ai[r], inv_t, bvi); RG_PIN(ti[r]); }
+            else if constexpr (j == 17) { th[r] = fmaf(ag[r], inv_t, bvh); RG_PIN(th[r]); }
+            else if constexpr (j == 18) { uu[r] = fmaf(rg[r], th[r], ti[r]); RG_PIN(uu[r]); }
+            else if constexpr (j == 19) { e3[r] = __builtin_amdgcn_exp2f(uu[r]); RG_PIN(e3[r]); }
+            else if constexpr (j == 20) { uu[r] = 1.0f + e3[r]; RG_PIN(uu[r]); }
+            else if constexpr (j == 21) { e3[r] = __builtin_amdgcn_rcpf(uu[r]); RG_PIN(e3[r]); }
+            else if constexpr (j == 22) { ng[r] = fmaf(2.0f, e3[r], -1.0f); RG_PIN(ng[r]); }
+            else if constexpr (j == 23) { uu[r] = hf[4 * pb + r] - ng[r]; RG_PIN(uu[r]); }
+            else { hnv[r] = fmaf(zg[r], uu[r], ng[r]); RG_PIN(hnv[r]); }           // (1 - z) n + z h  (the old state stays in registers)
+          } else {
 #pragma unroll
-    for (int ob = 0; ob < NB; ++ob) {
-      f32x4 c[3] = {zero4, zero4, zero4}, e[3] = {zero4, zero4, zero4};      // r, z, W_in x
-      f32x4 cg[3] = {zero4, zero4, zero4}, eg[3] = {zero4, zero4, zero4};    // (r, z again), W_hn h
-      const bool last = ob == NB - 1;
-      if (hh) issue(32 + ob, 40 + ob, 48 + ob);
-      else if (!last) issue(8 + ob + 1, 16 + ob + 1, 24 + ob + 1);
-      else issue(0, 1, 2);                                   // the next round's first chunk (dropped at its top)
-      mma3(X, c, e);
-      if (hh || !last) publish(); else __syncthreads();
-      if (hh) {
-        if (!last) issue(8 + ob + 1, 16 + ob + 1, 24 + ob + 1);
-        else issue(0, 1, 2);
-        mma3(H, cg, eg);
-        if (!last) publish(); else __syncthreads();
-      }
-      // r and z gates: W_i. x + W_h. h in one sum; the n gate keeps its two products apart
-      f32x4 ar = c[0], az = c[1], ai = c[2], ag = cg[2];
+            for (int r = 0; r < 4; ++r) hn[4 * pb + r] = hnv[r];
+            const u32x4 bits = {__float_as_uint(hnv[0]), __float_as_uint(hnv[1]), __float_as_uint(hnv[2]), __float_as_uint(hnv[3])};
+            __builtin_amdgcn_raw_buffer_store_b128(bits, r_out, (lane_off + 4u * pb) * 16u, 0, 0);
+          }
+        };
+        auto no_op = [&](auto) {};
+        if constexpr (ob < NB) {
+          constexpr bool last = ob == NB - 1;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        ar[r] = fmaf(e[0][r] + eg[0][r], LO8_INV, ar[r] + cg[0][r]);
-        az[r] = fmaf(e[1][r] + eg[1][r], LO8_INV, az[r] + cg[1][r]);
-      }
-      join(ai, e[2]);
-      join(ag, eg[2]);
-      const float4 br = *reinterpret_cast<const float4*>(bias_l + 0 * DP + 16 * ob + 4 * hq);
-      const float4 bz = *reinterpret_cast<const float4*>(bias_l + 1 * DP + 16 * ob + 4 * hq);
-      const float4 bi = *reinterpret_cast<const float4*>(bias_l + 2 * DP + 16 * ob + 4 * hq);
-      const float4 bh = *reinterpret_cast<const float4*>(bias_l + 3 * DP + 16 * ob + 4 * hq);
-      const float brv[4] = {br.x, br.y, br.z, br.w}, bzv[4] = {bz.x, bz.y, bz.z, bz.w};
-      const float biv[4] = {bi.x, bi.y, bi.z, bi.w}, bhv[4] = {bh.x, bh.y, bh.z, bh.w};
-      float hnv[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float rg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(ar[r], inv_s, brv[r])));
-        const float zg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(az[r], inv_s, bzv[r])));
-        const float ti = fmaf(ai[r], inv_t, biv[r]);
-        const float th = fmaf(ag[r], inv_t, bhv[r]);
-        const float ng = fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(fmaf(rg, th, ti))), -1.0f);
-        hnv[r] = fmaf(zg, hf[4 * ob + r] - ng, ng);       // (1 - z) n + z h  (one wave per SIMD: the old state stays in registers)
-        hn[4 * ob + r] = hnv[r];
-      }
-      if (node_ok) (A.hidden_out + row0 * S)[lane_off + 4 * ob] = make_float4(hnv[0], hnv[1], hnv[2], hnv[3]);
-    }
+          for (int q = 0; q < 4; ++q) { P[cs][q][0] = zero4; P[cs][q][1] = zero4; P[cs][q][2] = zero4; }
+          // operations of block ob - 1 behind this block's MFMAs: all of them behind the first chunk when there is no second one
+          constexpr int n_first = ob == 0 ? 0 : (HH ? NOPS / 2 : NOPS);
+          if constexpr (HH) issue(32 + ob, 40 + ob, 48 + ob);
+          else if constexpr (!last) issue(8 + ob + 1, 16 + ob + 1, 24 + ob + 1);
+          else issue(0, 1, 2);                                   // the next round's first chunk (dropped at its top)
+          if constexpr (ob == 0) mma3_ops(X, P[cs][0], P[cs][1], std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, no_op);
+          else mma3_ops(X, P[cs][0], P[cs][1], std::integral_constant<int, 0>{}, std::integral_constant<int, n_first>{}, gate_op);
+          if constexpr (HH || !last) publish(); else __syncthreads();
+          if constexpr (HH) {
+            if constexpr (!last) issue(8 + ob + 1, 16 + ob + 1, 24 + ob + 1);
+            else issue(0, 1, 2);
+            if constexpr (ob == 0) mma3_ops(H, P[cs][2], P[cs][3], std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, no_op);
+            else mma3_ops(H, P[cs][2], P[cs][3], std::integral_constant<int, n_first>{}, std::integral_constant<int, NOPS>{}, gate_op);
+            if constexpr (!last) publish(); else __syncthreads();
+          }
+        } else {
+          static_for<NOPS>(gate_op);                             // the last block's gates: nothing left to hide them behind
+        }
+      });
+    };
+    if (hh) gate_loop(std::true_type{}); else gate_loop(std::false_type{});
 
     // ---- projections of the new state (at scale 2^14) -------------------------------------------------------------------------------------
     if (A.Ws || A.W_final) split_frag(hn, 16384.0f, X);
