@@ -314,6 +314,20 @@ int rg_dense_train_fwd(int64_t n, int32_t d, const float* agg, const float* hidd
                        const float* W_h, int32_t act, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
                        const float* mask, float* hidden_out, float* x_out, float* gates_ws_out, void* stream);
 
+/* rg_dense_train_fwd that also emits the NEXT layer's hoisted attention projection of the new state, as rg_dense_fwd does in inference:
+ * a_s_out [n, ap] = hidden_out Ws_next^T (Ws_next [attn_dim, d], models.py:16,33; columns attn_dim .. ap - 1 are zero; attn_dim <= 16,
+ * ap = attn_dim rounded up to a multiple of 4). */
+int rg_dense_train_fwd_as(int64_t n, int32_t d, const float* agg, const float* hidden_prev, const int32_t* prev_idx,
+                          const float* W_h, int32_t act, const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh,
+                          const float* mask, const float* Ws_next, int32_t attn_dim, int32_t ap,
+                          float* hidden_out, float* x_out, float* gates_ws_out, float* a_s_out, void* stream);
+
+/* out[r, :n] = base[r, :n] + g[r, :k] W[:k, :n] for n_rows node rows (row strides ldb / ldg / ldo in floats): the new state's gradient
+ * through a_s = hidden Ws_attn^T added to the gradient it already carries (autograd of models.py:33).  k <= 32, n <= 128, n % 4 == 0;
+ * out may alias base. */
+int rg_rows_addmm(const float* base, int64_t ldb, const float* g, int64_t ldg, int32_t k, const float* W, int32_t n, int64_t n_rows,
+                  float* out, int64_t ldo, void* stream);
+
 /* Adjoint of rg_dense_train_fwd for the node-row quantities (autograd of models.py:41,81-83): from grad_hidden [n,d] and the saved
  * x / gates_ws (/ mask, keep = 1 - p) it writes grad_gates_i, grad_gates_h [n,3d] (GRU pre-activation gradients, for the weight and
  * bias gradients the caller forms), grad_pre [n,d] (gradient at W_h's output, for dW_h), grad_agg [n,d] and grad_h0 [n,d] (the

@@ -392,22 +392,24 @@ extern "C" int rg_dense_fwd_dev(int64_t n_cap, const int32_t* n_dev, int64_t n_h
                         a_s_out, W_final, nodes, n_ent, scores_all, hidden_out, precision, scratch, scratch_bytes, stream);
 }
 
-extern "C" int rg_dense_train_fwd(int64_t n, int32_t d, const float* agg, const float* hidden_prev, const int32_t* prev_idx,
-                                  const float* W_h, int32_t act, const float* w_ih, const float* w_hh, const float* b_ih,
-                                  const float* b_hh, const float* mask, float* hidden_out, float* x_out, float* gates_ws_out,
-                                  void* stream) {
-  RG_CHECK(agg && W_h && w_ih && w_hh && b_ih && b_hh && hidden_out && x_out && gates_ws_out, "rg_dense_train_fwd: NULL argument");
-  RG_CHECK(!prev_idx || hidden_prev, "rg_dense_train_fwd: prev_idx given without hidden_prev");
-  RG_CHECK((d >= 16 && d <= 64 && d % 4 == 0) || d == 128, "rg_dense_train_fwd: hidden_dim %d not supported (16..64 in steps of 4, or 128)", d);
-  RG_CHECK(act >= 0 && act <= 2, "rg_dense_train_fwd: act=%d", act);
+static int dense_train_fwd_impl(const char* who, int64_t n, int32_t d, const float* agg, const float* hidden_prev, const int32_t* prev_idx,
+                                const float* W_h, int32_t act, const float* w_ih, const float* w_hh, const float* b_ih,
+                                const float* b_hh, const float* mask, const float* Ws_next, int32_t attn_dim, int32_t ap,
+                                float* hidden_out, float* x_out, float* gates_ws_out, float* a_s_out, void* stream) {
+  RG_CHECK(agg && W_h && w_ih && w_hh && b_ih && b_hh && hidden_out && x_out && gates_ws_out, "%s: NULL argument", who);
+  RG_CHECK(!prev_idx || hidden_prev, "%s: prev_idx given without hidden_prev", who);
+  RG_CHECK((d >= 16 && d <= 64 && d % 4 == 0) || d == 128, "%s: hidden_dim %d not supported (16..64 in steps of 4, or 128)", who, d);
+  RG_CHECK(act >= 0 && act <= 2, "%s: act=%d", who, act);
+  RG_CHECK(!Ws_next || (a_s_out && attn_dim >= 1 && attn_dim <= 16 && ap >= attn_dim && ap % 4 == 0 && ap <= 16),
+           "%s: Ws_next needs a_s_out, 1 <= attn_dim <= 16 and ap = attn_dim padded to a multiple of 4 (got attn_dim=%d ap=%d)", who, attn_dim, ap);
   RG_CHECK((((uintptr_t)agg | (uintptr_t)hidden_prev | (uintptr_t)hidden_out | (uintptr_t)x_out | (uintptr_t)gates_ws_out |
-             (uintptr_t)mask) & 15) == 0, "rg_dense_train_fwd: float buffers must be 16-B aligned");
+             (uintptr_t)mask | (uintptr_t)a_s_out) & 15) == 0, "%s: float buffers must be 16-B aligned", who);
   if (n == 0) return 0;
   DenseArgs A;
   A.n = n; A.n_dev = nullptr; A.d = d; A.ld4 = d / 4;
   A.agg = (const float4*)agg; A.hprev = (const float4*)hidden_prev; A.prev_idx = prev_idx;
   A.W_h = W_h; A.w_ih = w_ih; A.w_hh = w_hh; A.b_ih = b_ih; A.b_hh = b_hh;
-  A.Ws = nullptr; A.attn = 0; A.ap = 0; A.a_s_out = nullptr;
+  A.Ws = Ws_next; A.attn = Ws_next ? attn_dim : 0; A.ap = Ws_next ? ap : 0; A.a_s_out = Ws_next ? a_s_out : nullptr;
   A.W_final = nullptr; A.nodes = nullptr; A.n_ent = 0; A.scores = nullptr;
   A.hidden_out = (float4*)hidden_out; A.act = act;
   A.n_tiles = (int)rg::ceil_div(n, 16);
@@ -415,4 +417,23 @@ extern "C" int rg_dense_train_fwd(int64_t n, int32_t d, const float* agg, const 
   hipStream_t s = (hipStream_t)stream;
   if (d == 128) return rg::dense128_launch(A, s);
   return d <= 32 ? launch<2, true>(A, s) : launch<4, true>(A, s);
+}
+
+extern "C" int rg_dense_train_fwd(int64_t n, int32_t d, const float* agg, const float* hidden_prev, const int32_t* prev_idx,
+                                  const float* W_h, int32_t act, const float* w_ih, const float* w_hh, const float* b_ih,
+                                  const float* b_hh, const float* mask, float* hidden_out, float* x_out, float* gates_ws_out,
+                                  void* stream) {
+  return dense_train_fwd_impl("rg_dense_train_fwd", n, d, agg, hidden_prev, prev_idx, W_h, act, w_ih, w_hh, b_ih, b_hh, mask, nullptr, 0, 0,
+                              hidden_out, x_out, gates_ws_out, nullptr, stream);
+}
+
+// ... and the next layer's attention projection of the new state (models.py:33, Ws_attn hoisted per node as in rg_dense_fwd):
+// a_s_out [n, ap] = hidden_out Ws_next^T, columns attn_dim .. ap - 1 zero
+extern "C" int rg_dense_train_fwd_as(int64_t n, int32_t d, const float* agg, const float* hidden_prev, const int32_t* prev_idx,
+                                     const float* W_h, int32_t act, const float* w_ih, const float* w_hh, const float* b_ih,
+                                     const float* b_hh, const float* mask, const float* Ws_next, int32_t attn_dim, int32_t ap,
+                                     float* hidden_out, float* x_out, float* gates_ws_out, float* a_s_out, void* stream) {
+  RG_CHECK(Ws_next && a_s_out, "rg_dense_train_fwd_as: NULL Ws_next / a_s_out (use rg_dense_train_fwd)");
+  return dense_train_fwd_impl("rg_dense_train_fwd_as", n, d, agg, hidden_prev, prev_idx, W_h, act, w_ih, w_hh, b_ih, b_hh, mask, Ws_next,
+                              attn_dim, ap, hidden_out, x_out, gates_ws_out, a_s_out, stream);
 }

@@ -183,3 +183,45 @@ extern "C" int rg_gram_tn(const float* g, int64_t ldg, int32_t m, const float* x
   RG_LAUNCH_CHECK();
   return 0;
 }
+
+// out[r, :n] = base[r, :n] + g[r, :k] W[:k, :n]  for node-row matrices (the gradient of the new state through the next layer's hoisted
+// attention projection, added to the gradient it already carries: autograd of models.py:33 for a_s = hidden Ws_attn^T).  k <= 32,
+// n <= 128 and a multiple of 4; W in LDS, one thread per four columns of a row: the pass is bound by its 2 n + k floats per row.
+namespace {
+__global__ __launch_bounds__(256) void rows_addmm_kernel(const float* __restrict__ base, int64_t ldb, const float* __restrict__ g, int64_t ldg,
+                                                         int k, const float* __restrict__ W, int n, int64_t n_rows, float* __restrict__ out,
+                                                         int64_t ldo) {
+  __shared__ float4 w_l[32 * 32];
+  const int n4 = n / 4;
+  for (int i = threadIdx.x; i < k * n4; i += 256) w_l[i] = reinterpret_cast<const float4*>(W)[i];
+  __syncthreads();
+  const int64_t per_block = 256 / n4;                    // rows per workgroup pass
+  const int c = threadIdx.x % n4, rl = threadIdx.x / n4;
+  if (rl >= per_block) return;
+  for (int64_t r = (int64_t)blockIdx.x * per_block + rl; r < n_rows; r += (int64_t)gridDim.x * per_block) {
+    float4 acc = *reinterpret_cast<const float4*>(base + r * ldb + 4 * c);
+    const float* gr = g + r * ldg;
+    for (int j = 0; j < k; ++j) {
+      const float gj = gr[j];
+      const float4 w = w_l[j * n4 + c];
+      acc.x = fmaf(gj, w.x, acc.x); acc.y = fmaf(gj, w.y, acc.y); acc.z = fmaf(gj, w.z, acc.z); acc.w = fmaf(gj, w.w, acc.w);
+    }
+    *reinterpret_cast<float4*>(out + r * ldo + 4 * c) = acc;
+  }
+}
+}  // namespace
+
+extern "C" int rg_rows_addmm(const float* base, int64_t ldb, const float* g, int64_t ldg, int32_t k, const float* W, int32_t n,
+                             int64_t n_rows, float* out, int64_t ldo, void* stream) {
+  RG_CHECK(base && g && W && out && n_rows >= 0, "rg_rows_addmm: NULL argument");
+  RG_CHECK(k >= 1 && k <= 32 && n >= 4 && n <= 128 && n % 4 == 0, "rg_rows_addmm: k=%d (1..32) n=%d (4..128, multiple of 4)", k, n);
+  RG_CHECK(ldb >= n && ldo >= n && ldg >= k && ldb % 4 == 0 && ldo % 4 == 0, "rg_rows_addmm: ldb=%lld ldo=%lld (>= n, multiples of 4) ldg=%lld",
+           (long long)ldb, (long long)ldo, (long long)ldg);
+  RG_CHECK((((uintptr_t)base | (uintptr_t)out | (uintptr_t)W) & 15) == 0, "rg_rows_addmm: base / out / W must be 16-B aligned");
+  if (n_rows == 0) return 0;
+  const int64_t per_block = 256 / (n / 4);
+  const int grid = (int)std::max<int64_t>(std::min<int64_t>(rg::ceil_div(n_rows, per_block), 256 * 8), 1);
+  hipLaunchKernelGGL(rows_addmm_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, base, ldb, g, ldg, k, W, n, n_rows, out, ldo);
+  RG_LAUNCH_CHECK();
+  return 0;
+}

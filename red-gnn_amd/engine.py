@@ -601,19 +601,42 @@ def dense_train_supported(d, act):
     return ((16 <= d <= 64 and d % 4 == 0) or d == 128) and act in ("idd", "relu", "tanh")
 
 
-def dense_train_fwd(agg, hidden_prev, prev_idx, W_h, act, gate, mask=None):
-    """rg_dense_train_fwd: (hidden_new [n,d], x [n,d], gates workspace [n,5d]) for the training step's dense part."""
+def dense_train_fwd(agg, hidden_prev, prev_idx, W_h, act, gate, mask=None, Ws_next=None):
+    """rg_dense_train_fwd: (hidden_new [n,d], x [n,d], gates workspace [n,5d]) for the training step's dense part; with Ws_next
+    [attn, d] (attn <= 16) also a_s [n, ap] = hidden_new Ws_next^T, the next layer's hoisted attention projection
+    (rg_dense_train_fwd_as), as a fourth element (None without Ws_next)."""
     n, d = agg.shape
     dev = agg.device
     hidden = torch.empty((n, d), dtype=torch.float32, device=dev)
     x = torch.empty((n, d), dtype=torch.float32, device=dev)
     ws = torch.empty((n, 5 * d), dtype=torch.float32, device=dev)
     c = lambda t: None if t is None else t.detach().contiguous()
-    _lib.check(_lib.lib().rg_dense_train_fwd(n, d, _lib.ptr(c(agg)), _lib.ptr(c(hidden_prev)), _lib.ptr(prev_idx), _lib.ptr(c(W_h)),
-                                             {"idd": 0, "relu": 1, "tanh": 2}[act], _lib.ptr(c(gate.weight_ih_l0)),
-                                             _lib.ptr(c(gate.weight_hh_l0)), _lib.ptr(c(gate.bias_ih_l0)), _lib.ptr(c(gate.bias_hh_l0)),
-                                             _lib.ptr(c(mask)), _lib.ptr(hidden), _lib.ptr(x), _lib.ptr(ws), _lib.stream_ptr()))
-    return hidden, x, ws
+    common = (n, d, _lib.ptr(c(agg)), _lib.ptr(c(hidden_prev)), _lib.ptr(prev_idx), _lib.ptr(c(W_h)),
+              {"idd": 0, "relu": 1, "tanh": 2}[act], _lib.ptr(c(gate.weight_ih_l0)), _lib.ptr(c(gate.weight_hh_l0)),
+              _lib.ptr(c(gate.bias_ih_l0)), _lib.ptr(c(gate.bias_hh_l0)), _lib.ptr(c(mask)))
+    if Ws_next is None:
+        _lib.check(_lib.lib().rg_dense_train_fwd(*common, _lib.ptr(hidden), _lib.ptr(x), _lib.ptr(ws), _lib.stream_ptr()))
+        return hidden, x, ws, None
+    attn = Ws_next.shape[0]
+    ap = (attn + 3) // 4 * 4
+    a_s = torch.empty((n, ap), dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib().rg_dense_train_fwd_as(*common, _lib.ptr(c(Ws_next)), attn, ap, _lib.ptr(hidden), _lib.ptr(x), _lib.ptr(ws),
+                                                _lib.ptr(a_s), _lib.stream_ptr()))
+    return hidden, x, ws, a_s
+
+
+def rows_addmm(base, g, W):
+    """base + g @ W for node-row matrices base [N, n], g [N, k] (k <= 32; rows may be spaced, unit-stride columns), W [k, n]: one HIP
+    pass (rg_rows_addmm).  Returns a new [N, n] tensor."""
+    assert base.is_cuda and base.dtype == g.dtype == W.dtype == torch.float32 and base.stride(1) == 1 and g.stride(1) == 1
+    n_rows, n = base.shape
+    k = W.shape[0]
+    assert g.shape[0] == n_rows and g.shape[1] >= k and W.shape[1] == n
+    out = torch.empty((n_rows, n), dtype=torch.float32, device=base.device)
+    Wc = W.detach().contiguous()
+    _lib.check(_lib.lib().rg_rows_addmm(C.c_void_p(base.data_ptr()), base.stride(0), C.c_void_p(g.data_ptr()), g.stride(0), k, _lib.ptr(Wc), n,
+                                        n_rows, _lib.ptr(out), n, _lib.stream_ptr()))
+    return out
 
 
 def dense_train_bwd_supported(d):

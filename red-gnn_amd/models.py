@@ -139,18 +139,29 @@ class _DenseStep(torch.autograd.Function):
     old node is exactly one new node)."""
 
     @staticmethod
-    def forward(ctx, agg, hidden_prev, W_h, w_ih, w_hh, b_ih, b_hh, prev_idx, old_new, mask, act, gate, keep):
+    def forward(ctx, agg, hidden_prev, W_h, w_ih, w_hh, b_ih, b_hh, Ws_next, prev_idx, old_new, mask, act, gate, keep):
+        """Ws_next: the NEXT layer's Ws_attn.weight [attn, d] or None.  With it the kernel also emits a_s = hidden_new Ws_next^T
+        (the hoisted attention projection, as the inference kernel does) and the step returns (hidden_new, a_s [n, ap])."""
         agg, hidden_prev = agg.contiguous(), hidden_prev.contiguous()
-        hidden, x, ws = engine.dense_train_fwd(agg, hidden_prev, prev_idx, W_h, act, gate, mask)
-        ctx.save_for_backward(agg, x, ws, W_h, w_ih, w_hh, old_new, mask if mask is not None else agg.new_zeros(0))
-        ctx.act, ctx.keep, ctx.n_old = act, keep, hidden_prev.shape[0]
-        return hidden
+        hidden, x, ws, a_s = engine.dense_train_fwd(agg, hidden_prev, prev_idx, W_h, act, gate, mask, Ws_next)
+        none = agg.new_zeros(0)
+        ctx.save_for_backward(agg, x, ws, W_h, w_ih, w_hh, old_new, mask if mask is not None else none,
+                              Ws_next if Ws_next is not None else none, hidden if Ws_next is not None else none)
+        ctx.act, ctx.keep, ctx.n_old, ctx.has_as = act, keep, hidden_prev.shape[0], Ws_next is not None
+        return (hidden, a_s) if Ws_next is not None else hidden
 
     @staticmethod
-    def backward(ctx, g_h):
-        agg, x, ws, W_h, w_ih, w_hh, old_new, mask = ctx.saved_tensors
+    def backward(ctx, g_h, g_as=None):
+        agg, x, ws, W_h, w_ih, w_hh, old_new, mask, Ws_next, hidden = ctx.saved_tensors
         n, d = agg.shape
         has_mask = mask.numel() > 0
+        g_ws = None
+        if ctx.has_as and g_as is not None:
+            # a_s = hidden Ws_next^T: its gradient joins the new state's (one HIP pass), Ws_next's is a sum over the rows
+            a = Ws_next.shape[0]
+            g_as = g_as.contiguous()
+            g_ws = _gram_tn(g_as[:, :a], hidden)
+            g_h = engine.rows_addmm(g_h.contiguous(), g_as, Ws_next) if n >= _TALL_ROWS else g_h + g_as[:, :a] @ Ws_next
         if engine.dense_train_bwd_supported(d) and n >= _FUSED_BWD_ROWS:
             # one fused kernel for everything per node row (rg_dense_train_bwd); the weight gradients below are sums over rows
             dgi, dgh, dpre, g_agg, dh0 = engine.dense_train_bwd(g_h, ws, x, mask if has_mask else None, ctx.keep, ctx.act, W_h, w_ih, w_hh)
@@ -159,7 +170,7 @@ class _DenseStep(torch.autograd.Function):
                 (g_wih, dbi), (g_whh, dbh) = engine.gram_tn(dgi, x, colsum=True), engine.gram_tn(dgh, h0, colsum=True)
                 g_wh = engine.gram_tn(dpre, agg)
                 g_prev = dh0[old_new.long()] if ctx.n_old else dh0.new_zeros((0, d))
-                return g_agg, g_prev, g_wh, g_wih, g_whh, dbi, dbh, None, None, None, None, None, None
+                return g_agg, g_prev, g_wh, g_wih, g_whh, dbi, dbh, g_ws, None, None, None, None, None, None
             dbi, dbh = dgi.sum(0), dgh.sum(0)
         else:
             dgi, dgh, dh0, dbi, dbh = torch.ops.aten._thnn_fused_gru_cell_backward(g_h.contiguous(), ws, True)
@@ -179,7 +190,7 @@ class _DenseStep(torch.autograd.Function):
         g_wih, g_whh = _gram_tn(dgi, x), _gram_tn(dgh, h0)
         g_wh = _gram_tn(dpre, agg)
         g_prev = dh0[old_new.long()] if ctx.n_old else dh0.new_zeros((0, d))
-        return g_agg, g_prev, g_wh, g_wih, g_whh, dbi, dbh, None, None, None, None, None, None
+        return g_agg, g_prev, g_wh, g_wih, g_whh, dbi, dbh, g_ws, None, None, None, None, None, None
 
 
 class GNNLayer(nn.Module):
@@ -203,13 +214,15 @@ class GNNLayer(nn.Module):
         return engine.layer_fwd(frontier, graph, level, nodes_new, hidden_p, rela_p, self.in_dim, a_s, a_r, a_q,
                                 self.w_alpha.weight.reshape(-1).contiguous(), self.w_alpha.bias, self.attn_dim)
 
-    def aggregate(self, q_rel, hidden, lease, graph, level, nodes_new, nodes_old):
-        """models.py:29-39 on the device; returns message_agg [n_new, in_dim].  ``lease``: engine.FrontierLease of the forward."""
+    def aggregate(self, q_rel, hidden, lease, graph, level, nodes_new, nodes_old, a_s=None):
+        """models.py:29-39 on the device; returns message_agg [n_new, in_dim].  ``lease``: engine.FrontierLease of the forward.
+        ``a_s`` [n_old, ap]: Ws_attn(hidden) when the previous layer's dense kernel already produced it (_DenseStep with Ws_next)."""
         d, a = self.in_dim, self.attn_dim
         ld, ap = max(16, _pad4(d)), pad_attn(a)
         rela = self.rela_embed.weight
         pad_rows = lambda w: F.pad(w, (0, 0, 0, ap - a)) if ap != a else w
-        a_s = tall_linear(hidden, pad_rows(self.Ws_attn.weight))                                # [n_old, ap]
+        if a_s is None:
+            a_s = tall_linear(hidden, pad_rows(self.Ws_attn.weight))                            # [n_old, ap]
         a_r = F.linear(rela, pad_rows(self.Wr_attn.weight))                                     # [2R+1, ap]
         a_q = F.linear(rela[q_rel], pad_rows(self.Wqr_attn.weight), F.pad(self.Wqr_attn.bias, (0, ap - a)))  # [B, ap]
         if ld != d:
@@ -397,6 +410,7 @@ class RED_GNN_trans(nn.Module):
         g = self.gate
         n_edges = []
         fused_train = self.fused_dense and engine.dense_train_supported(d, self.act_name)
+        a_s_next = None
         for i in range(self.n_layer):                                            # models.py:77
             n_new, n_e, _ = fr.expand(graph)                                     # models.py:78 (on the device)
             nodes, prev_idx, old_new = fr.nodes(want_prev=fused_train)
@@ -405,13 +419,16 @@ class RED_GNN_trans(nn.Module):
             layer = self.gnn_layers[i]
             if fused_train:
                 # models.py:80-83 with the dense part in one kernel: W_h + act, h0 carry (gather by prev_idx), dropout, GRU step
-                agg = layer.aggregate(q_rel, hidden, lease, graph, fr.level, nodes, nodes_old)
+                agg = layer.aggregate(q_rel, hidden, lease, graph, fr.level, nodes, nodes_old, a_s=a_s_next)
                 mask = None
                 if self.training and self.dropout.p > 0.0:
                     keep = 1.0 - self.dropout.p
                     mask = torch.empty((n_new, d), device=device).bernoulli_(keep).div_(keep)
-                hidden = _DenseStep.apply(agg, h0, layer.W_h.weight, g.weight_ih_l0, g.weight_hh_l0, g.bias_ih_l0, g.bias_hh_l0,
-                                          prev_idx, old_new, mask, self.act_name, g, 1.0 - self.dropout.p)
+                # the next layer's attention projection of the new state comes out of the same kernel (attn <= 16)
+                Ws_next = self.gnn_layers[i + 1].Ws_attn.weight if (i + 1 < self.n_layer and self.attn_dim <= 16) else None
+                out = _DenseStep.apply(agg, h0, layer.W_h.weight, g.weight_ih_l0, g.weight_hh_l0, g.bias_ih_l0, g.bias_hh_l0, Ws_next,
+                                       prev_idx, old_new, mask, self.act_name, g, 1.0 - self.dropout.p)
+                hidden, a_s_next = out if Ws_next is not None else (out, None)
             else:
                 hidden = layer(q_sub, q_rel, hidden, lease, graph, fr.level, nodes, nodes_old)             # models.py:80
                 h0 = torch.zeros((n_new, d), device=device).index_copy(0, old_new.long(), h0)           # models.py:81

@@ -1633,7 +1633,7 @@ def test_fused_training_dense_step_with_dropout_mask(act, d, n):
     w = torch.randn(n, d, device=dev)
     params = [agg, hprev, W_h, gate.weight_ih_l0, gate.weight_hh_l0, gate.bias_ih_l0, gate.bias_hh_l0]
 
-    out = _DenseStep.apply(agg, hprev, W_h, gate.weight_ih_l0, gate.weight_hh_l0, gate.bias_ih_l0, gate.bias_hh_l0, prev, old_new,
+    out = _DenseStep.apply(agg, hprev, W_h, gate.weight_ih_l0, gate.weight_hh_l0, gate.bias_ih_l0, gate.bias_hh_l0, None, prev, old_new,
                            mask, act, gate, keep)
     g1 = torch.autograd.grad((out * w).sum(), params)
     x = acts[act](agg @ W_h.t()) * mask
@@ -1644,3 +1644,23 @@ def test_fused_training_dense_step_with_dropout_mask(act, d, n):
     for a_, b_, name in zip(g1, g2, ["agg", "hidden_prev", "W_h", "w_ih", "w_hh", "b_ih", "b_hh"]):
         r = b_.cpu().numpy()
         np.testing.assert_allclose(a_.cpu().numpy(), r, rtol=2e-3, atol=2e-5 * max(1.0, float(np.abs(r).max())), err_msg=name)
+
+    # ... and with the next layer's attention projection emitted by the same kernel (rg_dense_train_fwd_as): a_s = hidden Ws^T, its
+    # gradient joining the new state's (rg_rows_addmm) and Ws's own (attention widths 5 and 16)
+    for attn in (5, 16):
+        Ws = (torch.randn(attn, d, device=dev) / d ** 0.5).requires_grad_(True)
+        ap = (attn + 3) // 4 * 4
+        wa = torch.randn(n, ap, device=dev)
+        out2, a_s = _DenseStep.apply(agg, hprev, W_h, gate.weight_ih_l0, gate.weight_hh_l0, gate.bias_ih_l0, gate.bias_hh_l0, Ws, prev, old_new,
+                                     mask, act, gate, keep)
+        assert a_s.shape == (n, ap) and torch.equal(out2, out)
+        g3 = torch.autograd.grad((out2 * w).sum() + (a_s * wa).sum(), params + [Ws])
+        ref2 = torch.gru_cell(acts[act](agg @ W_h.t()) * mask, torch.zeros(n, d, device=dev).index_copy(0, old_new.long(), hprev),
+                              gate.weight_ih_l0, gate.weight_hh_l0, gate.bias_ih_l0, gate.bias_hh_l0)
+        ref_as = ref2 @ Ws.t()
+        g4 = torch.autograd.grad((ref2 * w).sum() + (ref_as * wa[:, :attn]).sum(), params + [Ws])
+        np.testing.assert_allclose(a_s[:, :attn].detach().cpu().numpy(), ref_as.detach().cpu().numpy(), rtol=RTOL, atol=ATOL_H)
+        assert not a_s[:, attn:].any()
+        for a_, b_, name in zip(g3, g4, ["agg", "hidden_prev", "W_h", "w_ih", "w_hh", "b_ih", "b_hh", "Ws_next"]):
+            r = b_.cpu().numpy()
+            np.testing.assert_allclose(a_.cpu().numpy(), r, rtol=2e-3, atol=2e-5 * max(1.0, float(np.abs(r).max())), err_msg="%s attn=%d" % (name, attn))
