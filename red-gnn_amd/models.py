@@ -424,8 +424,12 @@ class RED_GNN_trans(nn.Module):
                 if self.training and self.dropout.p > 0.0:
                     keep = 1.0 - self.dropout.p
                     mask = torch.empty((n_new, d), device=device).bernoulli_(keep).div_(keep)
-                # the next layer's attention projection of the new state comes out of the same kernel (attn <= 16)
-                Ws_next = self.gnn_layers[i + 1].Ws_attn.weight if (i + 1 < self.n_layer and self.attn_dim <= 16) else None
+                # the next layer's attention projection of the new state comes out of the same kernel (attn <= 16) - and after the last
+                # layer the readout W_final (models.py:86) as a one-row projection
+                if i + 1 < self.n_layer:
+                    Ws_next = self.gnn_layers[i + 1].Ws_attn.weight if self.attn_dim <= 16 else None
+                else:
+                    Ws_next = self.W_final.weight
                 out = _DenseStep.apply(agg, h0, layer.W_h.weight, g.weight_ih_l0, g.weight_hh_l0, g.bias_ih_l0, g.bias_hh_l0, Ws_next,
                                        prev_idx, old_new, mask, self.act_name, g, 1.0 - self.dropout.p)
                 hidden, a_s_next = out if Ws_next is not None else (out, None)
@@ -438,7 +442,10 @@ class RED_GNN_trans(nn.Module):
             if trace is not None:
                 trace.append(dict(nodes=nodes, old_nodes_new_idx=old_new, n_edges=n_e, hidden=hidden))
             nodes_old = nodes
-        scores = tall_linear(hidden, self.W_final.weight).squeeze(-1)            # models.py:86
+        if fused_train and a_s_next is not None:
+            scores = a_s_next[:, 0]                                              # models.py:86, computed by the last dense step
+        else:
+            scores = tall_linear(hidden, self.W_final.weight).squeeze(-1)        # models.py:86
         key = nodes_old[:, 0].long() * n_ent + nodes_old[:, 1].long()
         scores_all = torch.zeros(n * n_ent, device=device).index_copy(0, key, scores)    # models.py:87-88
         self.last_stats = dict(n_edges=n_edges, n_nodes=int(nodes_old.shape[0]))
