@@ -152,6 +152,8 @@ class BaseModel(object):
         budget = _GraphedInference.budget(next(m.parameters()).device)
         fit = self.EVAL_LANES if need <= 0 else int(budget // (3 * need // 2 + 1))
         lanes = min(self.EVAL_LANES, max(8, n_batches // 8))      # (umls, 28 batches: 8 lanes 364 k queries/s, 16 lanes 305 k)
+        if need > (1 << 28):       # heavy forwards fill the chip by themselves: more lanes only compete for L2 (WN18RR, 1.7 GB per
+            lanes = min(lanes, 8)  # lane: 8 / 16 / 24 / 32 lanes 116 k / 101 k / 110 k / 101 k queries/s, tools/probe_eval_lanes.py)
         while lanes > 1 and lanes > fit:
             lanes //= 2
         return max(1, min(lanes, n_batches))
