@@ -336,6 +336,14 @@ int rg_dense_train_bwd(int64_t n, int32_t d, const float* grad_hidden, const flo
                        float keep, int32_t act, const float* W_h, const float* w_ih, const float* w_hh,
                        float* grad_gates_i, float* grad_gates_h, float* grad_pre, float* grad_agg, float* grad_h0, void* stream);
 
+/* rg_dense_train_bwd with two fewer passes over memory: grad_gates_hn [n,d] is only the n-gate block of the hidden-side gate gradients
+ * (their r and z blocks equal grad_gates_i's), and with prev_idx [n] (a node's row in the previous frontier or -1: rg_frontier_nodes)
+ * the carried state's gradient goes straight to grad_prev [n_old,d] (every row written exactly once; autograd of models.py:81's
+ * index_copy); prev_idx NULL: grad_prev is [n,d] = grad_h0. */
+int rg_dense_train_bwd2(int64_t n, int32_t d, const float* grad_hidden, const float* gates_ws, const float* x, const float* mask,
+                        float keep, int32_t act, const float* W_h, const float* w_ih, const float* w_hh, const int32_t* prev_idx,
+                        float* grad_gates_i, float* grad_gates_hn, float* grad_pre, float* grad_agg, float* grad_prev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,7 +15,7 @@ SYMBOLS = [
     "rg_graph_create", "rg_graph_create_device", "rg_graph_export_packs", "rg_tgraph_create", "rg_tgraph_create_excluding", "rg_graph_destroy", "rg_graph_n_fact", "rg_graph_export",
     "rg_frontier_workspace_bytes", "rg_frontier_create", "rg_frontier_destroy", "rg_frontier_reset",
     "rg_frontier_reset_nodes", "rg_frontier_expand", "rg_frontier_nodes", "rg_frontier_edges_scratch_bytes", "rg_frontier_edges",
-    "rg_layer_fwd_scratch_bytes", "rg_layer_fwd", "rg_layer_fwd_plan", "rg_tlayer_fwd", "rg_xlayer_fwd", "rg_frontier_set_window", "rg_layer_bwd_scratch_bytes", "rg_layer_bwd", "rg_tlayer_bwd_scratch_bytes", "rg_tlayer_bwd", "rg_xlayer_bwd", "rg_dense_fwd_supported", "rg_dense_scratch_bytes", "rg_dense_fwd", "rg_dense_fwd_dev", "rg_dense_train_fwd", "rg_dense_train_fwd_as", "rg_rows_addmm", "rg_dense_train_bwd", "rg_split3_roundtrip", "rg_split3_product_check", "rg_gram_tn_scratch_bytes", "rg_gram_tn", "rg_rank",
+    "rg_layer_fwd_scratch_bytes", "rg_layer_fwd", "rg_layer_fwd_plan", "rg_tlayer_fwd", "rg_xlayer_fwd", "rg_frontier_set_window", "rg_layer_bwd_scratch_bytes", "rg_layer_bwd", "rg_tlayer_bwd_scratch_bytes", "rg_tlayer_bwd", "rg_xlayer_bwd", "rg_dense_fwd_supported", "rg_dense_scratch_bytes", "rg_dense_fwd", "rg_dense_fwd_dev", "rg_dense_train_fwd", "rg_dense_train_fwd_as", "rg_rows_addmm", "rg_dense_train_bwd", "rg_dense_train_bwd2", "rg_split3_roundtrip", "rg_split3_product_check", "rg_gram_tn_scratch_bytes", "rg_gram_tn", "rg_rank",
     "rg_frontier_expand_async", "rg_frontier_expand_nodes_async", "rg_frontier_set_edge_hint", "rg_frontier_count_ptr", "rg_frontier_level_counts", "rg_attn_tables",
 ]
 
@@ -96,6 +96,7 @@ def lib():
     L.rg_dense_train_fwd_as.argtypes = [i64, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp]
     L.rg_rows_addmm.argtypes = [vp, i64, vp, i64, i32, vp, i32, i64, vp, i64, vp]
     L.rg_dense_train_bwd.argtypes = [i64, i32, vp, vp, vp, vp, C.c_float, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.rg_dense_train_bwd2.argtypes = [i64, i32, vp, vp, vp, vp, C.c_float, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.rg_rank.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp]
     L.rg_split3_roundtrip.argtypes = [vp, i64, i32, vp, vp, vp]
     L.rg_gram_tn_scratch_bytes.argtypes = [i32, i32]

@@ -33,6 +33,8 @@ struct DenseBwdArgs {
   float* dpre;           // [n][d]
   float* dagg;
   float* dh0;
+  float* dgh_n = nullptr;          // [n][d]: only the n-gate part of dgh (its r and z parts equal dgi's); then dgh is not written
+  const int32_t* prev_idx = nullptr;   // [n]: the node's row in the previous frontier or -1; then dh0 rows are scattered to dh0[prev_idx]
   int n_tiles;
 };
 
@@ -87,6 +89,7 @@ __global__ __launch_bounds__(DB_T, 2) void dense_bwd_kernel(DenseBwdArgs A) {
   for (int t = blockIdx.x * NW + wv; t < A.n_tiles; t += gridDim.x * NW) {
     const int64_t node = (int64_t)t * 16 + li;
     const bool in_n = node < A.n;
+    const int p_row = (A.prev_idx && in_n) ? A.prev_idx[node] : -1;
     f32x4 acc_dx[NB], acc_dh[NB];
 #pragma unroll
     for (int o = 0; o < NB; ++o) { acc_dx[o] = zero4; acc_dh[o] = zero4; }
@@ -130,9 +133,13 @@ __global__ __launch_bounds__(DB_T, 2) void dense_bwd_kernel(DenseBwdArgs A) {
         *reinterpret_cast<float4*>(gi) = make_float4(dr[0], dr[1], dr[2], dr[3]);
         *reinterpret_cast<float4*>(gi + d) = make_float4(dz[0], dz[1], dz[2], dz[3]);
         *reinterpret_cast<float4*>(gi + 2 * d) = make_float4(dn[0], dn[1], dn[2], dn[3]);
-        *reinterpret_cast<float4*>(gh) = make_float4(dr[0], dr[1], dr[2], dr[3]);
-        *reinterpret_cast<float4*>(gh + d) = make_float4(dz[0], dz[1], dz[2], dz[3]);
-        *reinterpret_cast<float4*>(gh + 2 * d) = make_float4(dnr[0], dnr[1], dnr[2], dnr[3]);
+        if (A.dgh_n) {
+          *reinterpret_cast<float4*>(A.dgh_n + node * (int64_t)d + col) = make_float4(dnr[0], dnr[1], dnr[2], dnr[3]);
+        } else {
+          *reinterpret_cast<float4*>(gh) = make_float4(dr[0], dr[1], dr[2], dr[3]);
+          *reinterpret_cast<float4*>(gh + d) = make_float4(dz[0], dz[1], dz[2], dz[3]);
+          *reinterpret_cast<float4*>(gh + 2 * d) = make_float4(dnr[0], dnr[1], dnr[2], dnr[3]);
+        }
       }
       // dx^T += W_ih^T[:, (g, ob)] dgi_g ;  dh^T += W_hh^T[:, (g, ob)] dgh_g      (k-block = this lane quarter's 4 columns)
 #pragma unroll
@@ -174,8 +181,12 @@ __global__ __launch_bounds__(DB_T, 2) void dense_bwd_kernel(DenseBwdArgs A) {
       }
       if (ok) {
         *reinterpret_cast<float4*>(A.dpre + node * d + col) = make_float4(dp[4 * o + 0], dp[4 * o + 1], dp[4 * o + 2], dp[4 * o + 3]);
-        *reinterpret_cast<float4*>(A.dh0 + node * d + col) =
-            make_float4(acc_dh[o][0] + gz[4 * o + 0], acc_dh[o][1] + gz[4 * o + 1], acc_dh[o][2] + gz[4 * o + 2], acc_dh[o][3] + gz[4 * o + 3]);
+        // (every node of the previous frontier is exactly one node of this one: with prev_idx the carried state's gradient lands in
+        // its own row of the previous level directly - no [n, d] intermediate and no gather pass)
+        const int64_t hrow = A.prev_idx ? (int64_t)p_row : node;
+        if (hrow >= 0)
+          *reinterpret_cast<float4*>(A.dh0 + hrow * d + col) =
+              make_float4(acc_dh[o][0] + gz[4 * o + 0], acc_dh[o][1] + gz[4 * o + 1], acc_dh[o][2] + gz[4 * o + 2], acc_dh[o][3] + gz[4 * o + 3]);
       }
     }
 
@@ -224,6 +235,32 @@ extern "C" int rg_dense_train_bwd(int64_t n, int32_t d, const float* grad_hidden
   A.n = n; A.d = d; A.g_h = grad_hidden; A.ws = gates_ws; A.x = x; A.mask = mask; A.keep = keep; A.act = act;
   A.W_h = W_h; A.w_ih = w_ih; A.w_hh = w_hh;
   A.dgi = grad_gates_i; A.dgh = grad_gates_h; A.dpre = grad_pre; A.dagg = grad_agg; A.dh0 = grad_h0;
+  A.n_tiles = (int)rg::ceil_div(n, 16);
+  hipStream_t s = (hipStream_t)stream;
+  return d <= 32 ? launch_bwd<2>(A, s) : launch_bwd<4>(A, s);
+}
+
+// rg_dense_train_bwd with two fewer passes over memory: grad_gates_hn [n, d] is only the n-gate block of the hidden-side gate gradients
+// (their r and z blocks equal grad_gates_i's, which the caller reads instead), and with prev_idx [n] (a node's row in the previous
+// frontier or -1) the carried state's gradient is written straight to grad_prev [n_old, d] (every previous node is exactly one node
+// of this level, so every row of grad_prev is written exactly once); prev_idx NULL: grad_prev is [n, d] = grad_h0 as before.
+extern "C" int rg_dense_train_bwd2(int64_t n, int32_t d, const float* grad_hidden, const float* gates_ws, const float* x,
+                                   const float* mask, float keep, int32_t act, const float* W_h, const float* w_ih,
+                                   const float* w_hh, const int32_t* prev_idx, float* grad_gates_i, float* grad_gates_hn, float* grad_pre,
+                                   float* grad_agg, float* grad_prev, void* stream) {
+  RG_CHECK(grad_hidden && gates_ws && x && W_h && w_ih && w_hh && grad_gates_i && grad_gates_hn && grad_pre && grad_agg && grad_prev,
+           "rg_dense_train_bwd2: NULL argument");
+  RG_CHECK(d >= 16 && d <= 64 && d % 4 == 0, "rg_dense_train_bwd2: hidden_dim %d not supported (16..64, multiple of 4)", d);
+  RG_CHECK(act >= 0 && act <= 2, "rg_dense_train_bwd2: act=%d", act);
+  RG_CHECK((((uintptr_t)grad_hidden | (uintptr_t)gates_ws | (uintptr_t)x | (uintptr_t)mask | (uintptr_t)grad_gates_i |
+             (uintptr_t)grad_gates_hn | (uintptr_t)grad_pre | (uintptr_t)grad_agg | (uintptr_t)grad_prev) & 15) == 0,
+           "rg_dense_train_bwd2: float buffers must be 16-B aligned");
+  if (n == 0) return 0;
+  DenseBwdArgs A;
+  A.n = n; A.d = d; A.g_h = grad_hidden; A.ws = gates_ws; A.x = x; A.mask = mask; A.keep = keep; A.act = act;
+  A.W_h = W_h; A.w_ih = w_ih; A.w_hh = w_hh;
+  A.dgi = grad_gates_i; A.dgh = nullptr; A.dgh_n = grad_gates_hn; A.dpre = grad_pre; A.dagg = grad_agg; A.dh0 = grad_prev;
+  A.prev_idx = prev_idx;
   A.n_tiles = (int)rg::ceil_div(n, 16);
   hipStream_t s = (hipStream_t)stream;
   return d <= 32 ? launch_bwd<2>(A, s) : launch_bwd<4>(A, s);

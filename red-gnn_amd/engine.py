@@ -639,6 +639,21 @@ def rows_addmm(base, g, W):
     return out
 
 
+def dense_train_bwd2(g_h, ws, x, mask, keep, act, W_h, w_ih, w_hh, prev_idx, n_old):
+    """rg_dense_train_bwd2: (dgi [n,3d], dgh_n [n,d], dpre [n,d], dagg [n,d], g_prev [n_old,d]) - the hidden-side gate gradients as their
+    n block only (r and z blocks = dgi's) and the carried state's gradient scattered to the previous frontier's rows by prev_idx."""
+    n, d = x.shape
+    dev = x.device
+    f = lambda rows, cols: torch.empty((rows, cols), dtype=torch.float32, device=dev)
+    dgi, dgh_n, dpre, dagg, g_prev = f(n, 3 * d), f(n, d), f(n, d), f(n, d), f(n_old, d)
+    c = lambda t: None if t is None else t.detach().contiguous()
+    _lib.check(_lib.lib().rg_dense_train_bwd2(n, d, _lib.ptr(c(g_h)), _lib.ptr(ws), _lib.ptr(x), _lib.ptr(c(mask)), float(keep),
+                                              {"idd": 0, "relu": 1, "tanh": 2}[act], _lib.ptr(c(W_h)), _lib.ptr(c(w_ih)), _lib.ptr(c(w_hh)),
+                                              _lib.ptr(prev_idx), _lib.ptr(dgi), _lib.ptr(dgh_n), _lib.ptr(dpre), _lib.ptr(dagg), _lib.ptr(g_prev),
+                                              _lib.stream_ptr()))
+    return dgi, dgh_n, dpre, dagg, g_prev
+
+
 def dense_train_bwd_supported(d):
     return 16 <= d <= 64 and d % 4 == 0
 

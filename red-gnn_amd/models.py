@@ -148,6 +148,7 @@ class _DenseStep(torch.autograd.Function):
         ctx.save_for_backward(agg, x, ws, W_h, w_ih, w_hh, old_new, mask if mask is not None else none,
                               Ws_next if Ws_next is not None else none, hidden if Ws_next is not None else none)
         ctx.act, ctx.keep, ctx.n_old, ctx.has_as = act, keep, hidden_prev.shape[0], Ws_next is not None
+        ctx.prev_idx = prev_idx
         return (hidden, a_s) if Ws_next is not None else hidden
 
     @staticmethod
@@ -162,6 +163,16 @@ class _DenseStep(torch.autograd.Function):
             g_as = g_as.contiguous()
             g_ws = _gram_tn(g_as[:, :a], hidden)
             g_h = engine.rows_addmm(g_h.contiguous(), g_as, Ws_next) if n >= _TALL_ROWS else g_h + g_as[:, :a] @ Ws_next
+        if engine.dense_train_bwd_supported(d) and n >= _TALL_ROWS and ctx.prev_idx is not None and ctx.n_old > 0:
+            # one fused kernel for everything per node row (rg_dense_train_bwd2): the hidden-side gate gradients as their n block only
+            # (the r and z blocks are dgi's) and the carried state's gradient straight into the previous frontier's rows
+            dgi, dgh_n, dpre, g_agg, g_prev = engine.dense_train_bwd2(g_h, ws, x, mask if has_mask else None, ctx.keep, ctx.act, W_h, w_ih,
+                                                                      w_hh, ctx.prev_idx, ctx.n_old)
+            h0 = ws.view(n, 5, d)[:, 3]                          # a column block of the workspace: no copy
+            g_wih, dbi = engine.gram_tn(dgi, x, colsum=True)
+            (g_rz, db_rz), (g_n, db_n) = engine.gram_tn(dgi[:, :2 * d], h0, colsum=True), engine.gram_tn(dgh_n, h0, colsum=True)
+            g_wh = engine.gram_tn(dpre, agg)
+            return g_agg, g_prev, g_wh, g_wih, torch.cat([g_rz, g_n]), dbi, torch.cat([db_rz, db_n]), g_ws, None, None, None, None, None, None
         if engine.dense_train_bwd_supported(d) and n >= _FUSED_BWD_ROWS:
             # one fused kernel for everything per node row (rg_dense_train_bwd); the weight gradients below are sums over rows
             dgi, dgh, dpre, g_agg, dh0 = engine.dense_train_bwd(g_h, ws, x, mask if has_mask else None, ctx.keep, ctx.act, W_h, w_ih, w_hh)
