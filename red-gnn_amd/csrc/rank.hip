@@ -19,18 +19,27 @@ __device__ __forceinline__ T wave_sum(T v) {
   return v;
 }
 
+// STAGED: the query's score row is copied to LDS on the pass that finds its minimum and every answer's counting pass reads it from
+// there (a row is read from memory once instead of once per answer + 1; rows up to 16 k entities)
+template <bool STAGED>
 __global__ __launch_bounds__(RT) void rank_kernel(const float* __restrict__ scores, int n_ent,
                                                   const int32_t* __restrict__ ans_ptr, const int32_t* __restrict__ ans_idx,
                                                   const int32_t* __restrict__ filt_ptr, const int32_t* __restrict__ filt_idx,
                                                   float* __restrict__ ranks) {
+  extern __shared__ float s_row[];
   __shared__ float s_min[RT / 64];
   __shared__ int s_cnt[3][RT / 64];
   const int q = blockIdx.x;
-  const float* row = scores + (int64_t)q * n_ent;
+  const float* grow = scores + (int64_t)q * n_ent;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 
   float mn = INFINITY;
-  for (int j = threadIdx.x; j < n_ent; j += RT) mn = fminf(mn, row[j]);
+  for (int j = threadIdx.x; j < n_ent; j += RT) {
+    const float v = grow[j];
+    if (STAGED) s_row[j] = v;
+    mn = fminf(mn, v);
+  }
+  const float* row = STAGED ? s_row : grow;
   for (int o = 32; o > 0; o >>= 1) mn = fminf(mn, __shfl_down(mn, o, 64));
   if (lane == 0) s_min[w] = mn;
   __syncthreads();
@@ -65,8 +74,12 @@ extern "C" int rg_rank(const float* scores, int32_t batch, int32_t n_ent, const 
                        const int32_t* filt_ptr, const int32_t* filt_idx, float* ranks_out, void* stream) {
   RG_CHECK(scores && ans_ptr && ans_idx && filt_ptr && filt_idx && ranks_out, "rg_rank: NULL argument");
   RG_CHECK(batch > 0 && n_ent > 0, "rg_rank: batch=%d n_ent=%d", batch, n_ent);
-  hipLaunchKernelGGL(rank_kernel, dim3(batch), dim3(RT), 0, (hipStream_t)stream, scores, n_ent, ans_ptr, ans_idx, filt_ptr,
-                     filt_idx, ranks_out);
+  if (n_ent <= 16384)
+    hipLaunchKernelGGL(rank_kernel<true>, dim3(batch), dim3(RT), (size_t)n_ent * sizeof(float), (hipStream_t)stream, scores, n_ent, ans_ptr,
+                       ans_idx, filt_ptr, filt_idx, ranks_out);
+  else
+    hipLaunchKernelGGL(rank_kernel<false>, dim3(batch), dim3(RT), 0, (hipStream_t)stream, scores, n_ent, ans_ptr, ans_idx, filt_ptr,
+                       filt_idx, ranks_out);
   RG_LAUNCH_CHECK();
   return 0;
 }
