@@ -288,7 +288,7 @@ struct Arena {
 extern "C" {
 
 const char* rg_last_error(void) { return rg::g_err.c_str(); }
-int rg_version(void) { return 9; }   // bumped whenever a kernel on the bench path changes: keys profiles/traffic_layer_fwd.json
+int rg_version(void) { return 10; }   // bumped whenever a kernel on the bench path changes: keys profiles/traffic_layer_fwd.json
 
 // rows (H, R, T [, TIME]) -> device CSRs, packed entries, virtual rows
 static int build_graph(int32_t n_ent, int32_t n_rel, int32_t n_rela_rows, const std::vector<int32_t>& H,

@@ -16,7 +16,7 @@ find $O/prof_train -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats_train_C
 rm -rf $O/prof_bench $O/prof_train
 echo "rocprof stats done"
 bash tools/pmc_traffic.sh C2 1024 > /dev/null 2>&1
-cp gpurun_out/r3_traffic_C2_1024/summary.json $O/pmc_traffic_C2_B1024_v9_summary.json
+cp gpurun_out/r3_traffic_C2_1024/summary.json $O/pmc_traffic_C2_B1024_v10_summary.json
 echo "pmc done"
 for extra in "" "--eval-collective allreduce" "--global-batch 256 --config C4" "--train --batch 128"; do
   tag=$(echo "$extra" | tr -d ' -' ); tag=${tag:-allgather}
