@@ -1,5 +1,5 @@
 """Where a word-parallel wave spends its cycles, per hop: needs a library built from the timing variant of layer_fwd_wp.hip
-(RG_LIB=red-gnn_amd/libredgnn_wpt.so: cycle counters around item load / fill / phase 1 / phase 2, exported as rg_debug_wp_timing)."""
+(python tools/make_wp_timing_variant.py, then RG_LIB=red-gnn_amd/libredgnn_wpt.so: cycle counters around item load / fill / phase 1 / phase 2, exported as rg_debug_wp_timing)."""
 import os, sys, ctypes
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
