@@ -745,6 +745,7 @@ def main():
             # this image's RCCL prints a version banner on STDOUT at init (NCCL_DEBUG=VERSION behaviour); the contract is ONE JSON line there
             if os.environ.get("NCCL_DEBUG", "").upper() in ("", "VERSION"):
                 os.environ["NCCL_DEBUG"] = "WARN"
+            os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")      # ... and whatever RCCL does print does not go to stdout
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(args.backend)
